@@ -1,0 +1,22 @@
+"""2048_q-learning_amd -- MI355X-native batched 2048 tabular Q-learning hot path.
+
+Drop-in for the path QLearningBase/environment/Game2048_env.py (step/reset) +
+QLearningBase/Agent/main.py (choose_action/update_q_value) of Rocco9999/2048_Q-Learning,
+running as hand-written HIP kernels for gfx950 behind the C ABI of include/q2048.h.
+
+The directory name is not a Python identifier; import it with
+    importlib.import_module("2048_q-learning_amd")
+or through the repo-root shim `q2048_amd.py`.  The package needs the in-tree
+csrc/libq2048_hip.so (built by __graft_entry__.build()); there is no CPU fallback.
+"""
+from . import _native
+from ._native import NativeError, build
+from .agent import BatchedQLearningAgent, EpsilonSchedule, QLearningAgent, stats_dict
+from .dist import Shard, allreduce_stats, shard_plan, weak_shard
+from .env import (AUX_DTYPE, BatchedGame2048Env, Game2048_env, boards_to_raw, raw_to_boards)
+
+__all__ = [
+    "BatchedGame2048Env", "Game2048_env", "BatchedQLearningAgent", "QLearningAgent",
+    "EpsilonSchedule", "stats_dict", "Shard", "shard_plan", "weak_shard", "allreduce_stats",
+    "boards_to_raw", "raw_to_boards", "AUX_DTYPE", "build", "NativeError",
+]

@@ -1,0 +1,125 @@
+"""ctypes binding of libq2048_hip.so (the C ABI of include/q2048.h).
+
+There is no CPU fallback: if the shared library is missing or does not export the ABI this
+module raises, and every op of the package fails loudly.  `build()` compiles it in-tree with
+hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_PKG, "csrc")
+INCLUDE = os.path.abspath(os.path.join(_PKG, "..", "include"))
+LIB_PATH = os.path.join(CSRC, "libq2048_hip.so")
+SOURCES = ["q2048_kernels.hip"]
+DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_luts.inc"]
+
+OK = 0
+STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
+FLAG_INDEPENDENT = 1
+ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
+ST_HIST0, NSTAT_I = 8, 32
+SF_RETURN, SF_RETURN_SQ, SF_REWARD, NSTAT_F = 0, 1, 2, 4
+SIZEOF_AUX, SIZEOF_SLOT = 16, 32
+
+
+class NativeError(RuntimeError):
+    """A q2048_* entry point returned an error code."""
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise FileNotFoundError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.join(INCLUDE, "q2048.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -shared: builds csrc/libq2048_hip.so in-tree."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-I", INCLUDE, "-I", CSRC, "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+_u8p, _f32p, _f64p = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
+_SIGNATURES = {
+    "q2048_abi_version": (C.c_int, []),
+    "q2048_strerror": (C.c_char_p, [C.c_int]),
+    "q2048_sizeof_aux": (C.c_size_t, []),
+    "q2048_sizeof_slot": (C.c_size_t, []),
+    "q2048_env_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint64,
+                                 C.c_uint64, C.c_void_p]),
+    "q2048_env_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                  C.c_uint64, C.c_uint64, C.c_void_p]),
+    "q2048_env_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                 C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "q2048_env_step_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "q2048_q_choose_draws": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_int, C.c_double, C.c_uint64, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "q2048_q_choose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double,
+                                 C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "q2048_q_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
+                                 C.c_double, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+    "q2048_q_lookup": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_uint64,
+                                 C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "q2048_fused_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                      C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                      C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "q2048_table_count": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "q2048_table_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads the library or raises; never substitutes another implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the ABI is incomplete
+        fn.restype, fn.argtypes = res, args
+    if L.q2048_abi_version() != 1:
+        raise ImportError(f"ABI version {L.q2048_abi_version()} != 1")
+    if L.q2048_sizeof_aux() != SIZEOF_AUX or L.q2048_sizeof_slot() != SIZEOF_SLOT:
+        raise ImportError("ABI struct sizes changed")
+    _lib = L
+    return L
+
+
+def check(code: int, what: str) -> None:
+    if code != OK:
+        raise NativeError(f"{what}: {lib().q2048_strerror(code).decode()} (code {code})")

@@ -1,0 +1,292 @@
+"""Tabular Q-learning agent on MI355X: the host-side mirror of QLearningBase/Agent/main.py
+(class QLearningAgent, :14-57).
+
+`BatchedQLearningAgent` keeps the reference's constructor arguments and method names
+(`choose_action`, `update_q_value`, `decay_exploration`, `q_table[state]`, `epsilon`) over B
+states at once, with the Q-table as a device open-addressed hash table; `fused_rollout` is the
+throughput entry point (whole loop body of Agent/main.py:91-101 in one launch).
+`QLearningAgent` is the one-state adapter with the reference's Python types."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .env import BatchedGame2048Env, _ptr, _require_gpu, _stream, raw_to_boards
+
+
+class EpsilonSchedule:
+    """QLearningAgent's exploration schedule (Agent/main.py:15-32, 45-57), host scalars.
+    Same arithmetic in the same order as the reference, so the values are bit-identical."""
+
+    def __init__(self, total_epochs, exploration_rate=1.0, exploration_min=0.01):
+        self.epsilon = exploration_rate                                        # :19
+        self.epsilon_min = exploration_min                                     # :20
+        self.total_epochs = total_epochs                                       # :22
+        self.first_decay_limit = total_epochs * 0.30                           # :25
+        self.second_decay_limit = total_epochs * 0.60                          # :26
+        self.third_decay_limit = total_epochs * 0.80                           # :27
+        self.slow_decay_1 = (exploration_rate - (exploration_min * 1.5)) / self.first_decay_limit
+        self.fast_decay = ((exploration_rate - exploration_min) - (exploration_min * 1.5)) / (
+            self.second_decay_limit - self.first_decay_limit)                  # :31
+        self.slow_decay_2 = (exploration_min * 1.1 - exploration_min) / (
+            self.third_decay_limit - self.second_decay_limit)                  # :32
+
+    def decay_exploration(self, current_epoch):
+        if current_epoch < self.first_decay_limit:                             # :46
+            self.epsilon = max(self.epsilon_min * 1.5, self.epsilon - self.slow_decay_1)
+        elif current_epoch < self.second_decay_limit:                          # :49
+            self.epsilon = max(self.epsilon_min * 1.1, self.epsilon - self.fast_decay)
+        elif current_epoch < self.third_decay_limit:                           # :52
+            self.epsilon = max(self.epsilon_min, self.epsilon - self.slow_decay_2)
+        else:
+            self.epsilon = self.epsilon_min                                    # :57
+
+
+class _QTableView:
+    """`agent.q_table[state]` (Agent/main.py:16,96): state = tuple of 4 tuples of raw tile
+    values; returns the 4 Q-values as float64 (zeros when the state was never updated)."""
+
+    def __init__(self, agent: "BatchedQLearningAgent"):
+        self._a = agent
+
+    def __getitem__(self, state) -> np.ndarray:
+        b = torch.from_numpy(raw_to_boards(np.asarray(state).reshape(1, 4, 4))).to(self._a.device)
+        return self._a.q_values(b, env_id0=self._a.env_id0)[0].double().cpu().numpy()
+
+    def __len__(self) -> int:
+        return self._a.table_size()
+
+
+class BatchedQLearningAgent:
+    """QLearningAgent over a batch.  Constructor arguments as Agent/main.py:15; extra keyword
+    arguments size and place the device table.
+
+    capacity_log2   the table has 2**capacity_log2 slots of 32 B, fixed at construction.  When an
+                    update finds no free slot within the probe limit it is dropped and counted
+                    (stats['drops'], status TABLE_FULL) -- never an exception.
+    independent     every env owns private rows (keys salted with its global id): B independent
+                    learners in one table, exactly B reference agents side by side."""
+
+    def __init__(self, total_epochs, action_space=4, learning_rate=0.1, discount_factor=0.9,
+                 exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 24,
+                 device="cuda", seed: int = 0, env_id0: int = 0, independent: bool = False):
+        self.device = _require_gpu(device)
+        if action_space != 4:
+            raise ValueError("the 2048 action space has 4 actions")
+        if not 4 <= capacity_log2 <= 40:
+            raise ValueError("capacity_log2 must be in [4, 40]")
+        self.action_space = action_space                                       # :21
+        self.lr = learning_rate                                                # :17
+        self.gamma = discount_factor                                           # :18
+        self.schedule = EpsilonSchedule(total_epochs, exploration_rate, exploration_min)
+        self.total_epochs = total_epochs
+        self.capacity_log2 = int(capacity_log2)
+        self.seed, self.env_id0 = int(seed), int(env_id0)
+        self.flags = N.FLAG_INDEPENDENT if independent else 0
+        self.ctr = 0  # choose_action calls so far = counter word of the step draws
+        self.table = torch.zeros((1 << self.capacity_log2, N.SIZEOF_SLOT), dtype=torch.uint8,
+                                 device=self.device)
+        self.stats_i = torch.zeros(N.NSTAT_I, dtype=torch.int64, device=self.device)
+        self.stats_f = torch.zeros(N.NSTAT_F, dtype=torch.float64, device=self.device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.q_table = _QTableView(self)
+
+    # -- reference surface ---------------------------------------------------------------
+    @property
+    def epsilon(self) -> float:
+        return self.schedule.epsilon
+
+    @epsilon.setter
+    def epsilon(self, v: float):
+        self.schedule.epsilon = float(v)
+
+    @property
+    def epsilon_min(self) -> float:
+        return self.schedule.epsilon_min
+
+    def decay_exploration(self, current_epoch) -> None:
+        self.schedule.decay_exploration(current_epoch)                         # :45-57
+
+    def choose_action(self, boards: torch.Tensor) -> torch.Tensor:
+        """choose_action (:34-38) for B states -> uint8 actions [B]."""
+        boards = self._boards(boards)
+        B = boards.shape[0]
+        actions = torch.empty(B, dtype=torch.uint8, device=self.device)
+        N.check(N.lib().q2048_q_choose(
+            _ptr(self.table), self.capacity_log2, _ptr(boards), B, 4, float(self.epsilon),
+            self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self.flags, _ptr(actions),
+            _ptr(self.status), _stream(self.device)), "q_choose")
+        self.ctr += 1
+        return actions
+
+    def update_q_value(self, boards, actions, reward, next_boards, done) -> None:
+        """update_q_value (:40-43) for B transitions."""
+        boards, next_boards = self._boards(boards), self._boards(next_boards)
+        B = boards.shape[0]
+        actions = self._vec(actions, torch.uint8, B, "actions")
+        reward = self._vec(reward, torch.float32, B, "reward")
+        done = self._vec(done, torch.uint8, B, "done")
+        N.check(N.lib().q2048_q_update(
+            _ptr(self.table), self.capacity_log2, _ptr(boards), _ptr(actions), _ptr(reward),
+            _ptr(next_boards), _ptr(done), B, 4, float(self.lr), float(self.gamma), self.env_id0,
+            self.flags, _ptr(self.stats_i), _ptr(self.status), _stream(self.device)), "q_update")
+
+    def q_values(self, boards: torch.Tensor, env_id0: int | None = None,
+                 return_found: bool = False):
+        """q_table[state] for B states -> float32 [B, 4] (zeros where absent)."""
+        boards = self._boards(boards)
+        B = boards.shape[0]
+        q = torch.empty((B, 4), dtype=torch.float32, device=self.device)
+        found = torch.empty(B, dtype=torch.uint8, device=self.device) if return_found else None
+        N.check(N.lib().q2048_q_lookup(
+            _ptr(self.table), self.capacity_log2, _ptr(boards), B, 4,
+            self.env_id0 if env_id0 is None else int(env_id0), self.flags, _ptr(q), _ptr(found),
+            _stream(self.device)), "q_lookup")
+        return (q, found.bool()) if return_found else q
+
+    # -- throughput entry point ----------------------------------------------------------
+    def fused_rollout(self, env: BatchedGame2048Env, steps: int) -> None:
+        """`steps` iterations of choose -> step -> update -> accumulate -> reset-on-done
+        (Agent/main.py:91-101, :81) for every env in ONE launch.  Statistics accumulate in
+        `stats_i` / `stats_f` on the device (read them with `stats()`)."""
+        if env.device != self.device:
+            raise ValueError("env and agent live on different devices")
+        if (env.seed, env.env_id0) != (self.seed, self.env_id0):
+            raise ValueError("env and agent must share seed and env_id0 (one draw stream per env)")
+        if env.ctr != self.ctr:
+            raise ValueError(f"env.ctr={env.ctr} and agent.ctr={self.ctr} are out of step")
+        N.check(N.lib().q2048_fused_rollout(
+            _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
+            4, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
+            self.env_id0, self.ctr & 0xFFFFFFFF, self.flags, _ptr(self.stats_i),
+            _ptr(self.stats_f), _ptr(self.status), _stream(self.device)), "fused_rollout")
+        env.ctr += int(steps)
+        self.ctr += int(steps)
+
+    # -- statistics / table access ---------------------------------------------------------
+    def stats(self, reset: bool = False) -> dict:
+        """Synchronising host copy of the device statistics."""
+        si = self.stats_i.cpu().numpy()
+        sf = self.stats_f.cpu().numpy()
+        if reset:
+            self.stats_i.zero_()
+            self.stats_f.zero_()
+        return stats_dict(si, sf)
+
+    def table_size(self) -> int:
+        """len(q_table): occupied slots."""
+        count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        N.check(N.lib().q2048_table_count(_ptr(self.table), self.capacity_log2, _ptr(count),
+                                          _stream(self.device)), "table_count")
+        return int(count.item())
+
+    def export_rows(self):
+        """All occupied rows: (keys uint64 [R], q float32 [R,4]) on the host."""
+        rows = self.table_size()
+        keys = torch.empty(max(rows, 1), dtype=torch.int64, device=self.device)
+        q = torch.empty((max(rows, 1), 4), dtype=torch.float32, device=self.device)
+        count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        N.check(N.lib().q2048_table_export(_ptr(self.table), self.capacity_log2, _ptr(keys),
+                                           _ptr(q), rows, _ptr(count), _stream(self.device)),
+                "table_export")
+        got = min(int(count.item()), rows)
+        return keys[:got].cpu().numpy().view(np.uint64), q[:got].cpu().numpy()
+
+    def export_dict(self) -> dict:
+        """The table in the reference's form: {tuple of 4 tuples of raw tile values ->
+        np.float64[4]} (Agent/main.py:16,82).  Shared-table mode only."""
+        if self.flags & N.FLAG_INDEPENDENT:
+            raise ValueError("salted keys of independent mode do not decode to boards")
+        keys, q = self.export_rows()
+        out = {}
+        for k, row in zip(keys.tolist(), q.astype(np.float64)):
+            cells = [(k >> (4 * c)) & 15 for c in range(16)]
+            raw = [0 if v == 0 else 1 << v for v in cells]
+            out[tuple(tuple(raw[4 * r:4 * r + 4]) for r in range(4))] = row
+        return out
+
+    def check_status(self) -> int:
+        s = int(self.status.item())
+        if s & N.STATUS_BAD_ACTION:
+            self.status.zero_()
+            raise ValueError("an action outside 0..3 was passed to update_q_value()")
+        return s
+
+    # -- argument plumbing -----------------------------------------------------------------
+    def _boards(self, b) -> torch.Tensor:
+        if not isinstance(b, torch.Tensor):
+            b = torch.as_tensor(np.asarray(b, dtype=np.uint8))
+        if b.dtype != torch.uint8:
+            raise TypeError("boards must be uint8 log2 tiles")
+        b = b.to(self.device)
+        if b.dim() != 2 or b.shape[1] != 16:
+            raise ValueError(f"boards must have shape (B, 16), got {tuple(b.shape)}")
+        return b.contiguous()
+
+    def _vec(self, v, dtype, B, name) -> torch.Tensor:
+        if not isinstance(v, torch.Tensor):
+            v = torch.as_tensor(v)
+        v = v.to(device=self.device, dtype=dtype).contiguous()
+        if v.shape != (B,):
+            raise ValueError(f"{name} must have shape ({B},), got {tuple(v.shape)}")
+        return v
+
+
+def stats_dict(si, sf) -> dict:
+    si = np.asarray(si, dtype=np.int64)
+    sf = np.asarray(sf, dtype=np.float64)
+    ep = int(si[N.ST_EPISODES])
+    return {
+        "steps": int(si[N.ST_STEPS]), "episodes": ep, "valid_moves": int(si[N.ST_VALID]),
+        "score_sum": int(si[N.ST_SCORE]), "inserts": int(si[N.ST_INSERTS]),
+        "drops": int(si[N.ST_DROPS]), "explored": int(si[N.ST_EXPLORE]),
+        "cas_retries": int(si[N.ST_CAS_RETRY]),
+        "max_tile_hist": {1 << k: int(v) for k, v in enumerate(si[N.ST_HIST0:N.ST_HIST0 + 24]) if v},
+        "return_sum": float(sf[N.SF_RETURN]), "return_sq_sum": float(sf[N.SF_RETURN_SQ]),
+        "reward_sum": float(sf[N.SF_REWARD]),
+        "mean_return": float(sf[N.SF_RETURN]) / ep if ep else float("nan"),
+        "mean_score": float(si[N.ST_SCORE]) / ep if ep else float("nan"),
+    }
+
+
+class QLearningAgent:
+    """One-state adapter with the reference's exact surface (Agent/main.py:14-57): states are
+    tuples of tuples of raw tile values, actions Python ints."""
+
+    def __init__(self, total_epochs, action_space, learning_rate=0.1, discount_factor=0.9,
+                 exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 22,
+                 device="cuda", seed: int = 0, env_id: int = 0):
+        self._b = BatchedQLearningAgent(total_epochs, action_space, learning_rate, discount_factor,
+                                        exploration_rate, exploration_min, capacity_log2, device,
+                                        seed, env_id)
+        self.q_table = self._b.q_table
+        self.action_space = action_space
+        self.total_epochs = total_epochs
+
+    lr = property(lambda self: self._b.lr)
+    gamma = property(lambda self: self._b.gamma)
+    epsilon_min = property(lambda self: self._b.epsilon_min)
+
+    @property
+    def epsilon(self) -> float:
+        return self._b.epsilon
+
+    @epsilon.setter
+    def epsilon(self, v):
+        self._b.epsilon = v
+
+    def _state(self, state) -> torch.Tensor:
+        return torch.from_numpy(raw_to_boards(np.asarray(state).reshape(1, 4, 4)))
+
+    def choose_action(self, state) -> int:
+        return int(self._b.choose_action(self._state(state)).item())
+
+    def update_q_value(self, state, action, reward, next_state, done) -> None:
+        if not 0 <= int(action) <= 3:
+            raise ValueError(f"action {action} outside 0..3")
+        self._b.update_q_value(self._state(state), [int(action)], [float(reward)],
+                               self._state(next_state), [bool(done)])
+
+    def decay_exploration(self, current_epoch) -> None:
+        self._b.decay_exploration(current_epoch)

@@ -1,0 +1,574 @@
+// q2048_kernels.hip -- gfx950 kernels + the C ABI of include/q2048.h.
+//
+// Layout in HBM (all caller-owned):
+//   boards  uint8[B][16]   one dwordx4 per lane, perfectly coalesced (1 KiB per wave access)
+//   aux     16 B per env   one dwordx4 per lane
+//   table   32 B slots     {u64 key, f32 q[4], u64 reserved}; random access, one 64-B line
+//                          per probe; linear probing keeps collisions in the same line
+// One board per lane.  Boards, aux and the carried Q row live in VGPRs for a whole launch;
+// per-step boolean statistics are wave ballots accumulated in SGPRs, rare per-episode
+// statistics go through LDS, and each block ends with one global atomic per statistic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "q2048.h"
+#include "q2048_core.hpp"
+
+namespace {
+using namespace q2048;
+
+constexpr int kBlock = 256;
+constexpr int kMaxProbe = 256;   // probe limit: beyond it a lookup reads "absent", an update drops
+constexpr int kMaxCas = 4096;    // TD compare-and-swap retries before the additive fallback
+
+static_assert(sizeof(q2048_aux) == 16 && sizeof(q2048_slot) == 32, "ABI layout");
+static_assert(sizeof(Aux) == sizeof(q2048_aux), "core/ABI aux mismatch");
+
+using u64 = unsigned long long;
+
+// ---------------------------------------------------------------------------------------------
+// coalesced 16-byte images
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ Board ld_board(const uint8_t* boards, int64_t i) {
+  const uint4 v = reinterpret_cast<const uint4*>(boards)[i];
+  return Board{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st_board(uint8_t* boards, int64_t i, const Board& b) {
+  reinterpret_cast<uint4*>(boards)[i] = make_uint4(b.r0, b.r1, b.r2, b.r3);
+}
+__device__ __forceinline__ Aux ld_aux(const q2048_aux* aux, int64_t i) {
+  const uint4 v = reinterpret_cast<const uint4*>(aux)[i];
+  return words_to_aux(Words4{v.x, v.y, v.z, v.w});
+}
+__device__ __forceinline__ void st_aux(q2048_aux* aux, int64_t i, const Aux& a) {
+  const Words4 w = aux_to_words(a);
+  reinterpret_cast<uint4*>(aux)[i] = make_uint4(w.w0, w.w1, w.w2, w.w3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hash table.  Readers use agent-scope relaxed loads (they bypass the per-CU L1, which other
+// CUs' atomics never refresh); writers use device-scope compare-and-swap.  Keys are written
+// once (0 -> key) and never change, so a stale read can only miss a brand-new row, which reads
+// as the zero row it still is for the reader.
+// ---------------------------------------------------------------------------------------------
+struct Row { float q0, q1, q2, q3; };
+
+__device__ __forceinline__ u64 ld_key(const q2048_slot* s) {
+  return __hip_atomic_load(const_cast<u64*>(reinterpret_cast<const u64*>(&s->key)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ Row ld_row(const q2048_slot* s) {
+  u64* p = const_cast<u64*>(reinterpret_cast<const u64*>(&s->q[0]));
+  const u64 a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return Row{bits_f32((uint32_t)a), bits_f32((uint32_t)(a >> 32)), bits_f32((uint32_t)b),
+             bits_f32((uint32_t)(b >> 32))};
+}
+__device__ __forceinline__ float row_get(const Row& r, int a) {
+  return a == 0 ? r.q0 : a == 1 ? r.q1 : a == 2 ? r.q2 : r.q3;
+}
+__device__ __forceinline__ void row_set(Row& r, int a, float v) {
+  r.q0 = a == 0 ? v : r.q0; r.q1 = a == 1 ? v : r.q1;
+  r.q2 = a == 2 ? v : r.q2; r.q3 = a == 3 ? v : r.q3;
+}
+
+// Lookup without insertion.  Returns the slot index, or -1 when the key is absent (row = 0).
+__device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask, u64 key, Row& row) {
+  u64 i = mix64(key) & mask;
+  row = Row{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < kMaxProbe; ++p) {
+    const u64 k = ld_key(&table[i]);
+    if (k == key) { row = ld_row(&table[i]); return (int64_t)i; }
+    if (k == 0ull) return -1;
+    i = (i + 1ull) & mask;
+  }
+  return -1;
+}
+
+// Find-or-create.  Returns the slot index or -1 (probe limit: the caller drops the update).
+__device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, u64 key, bool& inserted) {
+  u64 i = mix64(key) & mask;
+  inserted = false;
+  for (int p = 0; p < kMaxProbe; ++p) {
+    u64 k = ld_key(&table[i]);
+    if (k == 0ull) {
+      k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key);
+      if (k == 0ull) { inserted = true; return (int64_t)i; }
+    }
+    if (k == key) return (int64_t)i;
+    i = (i + 1ull) & mask;
+  }
+  return -1;
+}
+
+// update_q_value on one entry (Agent/main.py:43) against its CURRENT value.  `guess` is the
+// value this lane last saw; a failed compare-and-swap returns the live value and the update is
+// recomputed from it, so concurrent updates of one (s, a) serialise in some order.
+__device__ __forceinline__ float td_update(q2048_slot* slot, int a, float guess, float reward,
+                                           float max_next, bool done, double lr, double gamma,
+                                           uint32_t& retries) {
+  unsigned int* addr = reinterpret_cast<unsigned int*>(&slot->q[a]);
+  unsigned int expect = f32_bits(guess);
+  float nq = td_value(guess, reward, max_next, done, lr, gamma);
+  for (int it = 0; it < kMaxCas; ++it) {
+    const unsigned int prev = atomicCAS(addr, expect, f32_bits(nq));
+    if (prev == expect) return nq;
+    ++retries;
+    expect = prev;
+    nq = td_value(bits_f32(expect), reward, max_next, done, lr, gamma);
+  }
+  atomicAdd(&slot->q[a], nq - bits_f32(expect));  // extreme contention: keep the sample
+  return nq;
+}
+
+__device__ __forceinline__ u64 state_key(const Board& b, u64 salt, uint32_t* status) {
+  bool ov;
+  u64 k = pack_key(b, ov) ^ salt;
+  if (ov) atomicOr(status, Q2048_STATUS_TILE_OVERFLOW);
+  return k == 0ull ? 1ull : k;  // 0 marks an empty slot
+}
+
+__device__ __forceinline__ uint32_t wave_count(bool pred) {
+  return (uint32_t)__popcll(__ballot(pred));
+}
+
+// block-level statistics staging (LDS) and flush
+struct BlockStats {
+  u64 i[Q2048_NSTAT_I];
+  double f[Q2048_NSTAT_F];
+};
+__device__ __forceinline__ void stats_clear(BlockStats& s) {
+  if (threadIdx.x < Q2048_NSTAT_I) s.i[threadIdx.x] = 0ull;
+  if (threadIdx.x < Q2048_NSTAT_F) s.f[threadIdx.x] = 0.0;
+  __syncthreads();
+}
+__device__ __forceinline__ void stats_flush(BlockStats& s, int64_t* gi, double* gf) {
+  __syncthreads();
+  if (gi != nullptr && threadIdx.x < Q2048_NSTAT_I && s.i[threadIdx.x] != 0ull)
+    atomicAdd(reinterpret_cast<u64*>(gi) + threadIdx.x, s.i[threadIdx.x]);
+  if (gf != nullptr && threadIdx.x < Q2048_NSTAT_F && s.f[threadIdx.x] != 0.0)
+    atomicAdd(gf + threadIdx.x, s.f[threadIdx.x]);
+}
+__device__ __forceinline__ void episode_stats(BlockStats& s, const Aux& a, uint32_t max_l2) {
+  atomicAdd(&s.i[Q2048_ST_SCORE], (u64)(int64_t)a.score);
+  atomicAdd(&s.i[Q2048_ST_HIST0 + (max_l2 > 23u ? 23u : max_l2)], 1ull);
+  const double ret = (double)a.ep_return;
+  atomicAdd(&s.f[Q2048_SF_RETURN], ret);
+  atomicAdd(&s.f[Q2048_SF_RETURN_SQ], ret * ret);
+}
+
+// ---------------------------------------------------------------------------------------------
+// env kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_env_init(uint8_t* boards, q2048_aux* aux, int64_t B,
+                                                     uint64_t seed, uint64_t env_id0) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  Board b; Aux a;
+  init_env(b, a, seed, env_id0 + (uint64_t)i);
+  st_board(boards, i, b);
+  st_aux(aux, i, a);
+}
+
+__global__ __launch_bounds__(kBlock) void k_env_reset(uint8_t* boards, q2048_aux* aux,
+                                                      const uint8_t* mask, int64_t B, uint64_t seed,
+                                                      uint64_t env_id0) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  if (mask != nullptr && mask[i] == 0) return;
+  Board b = ld_board(boards, i);
+  Aux a = ld_aux(aux, i);
+  begin_episode(b, a, seed, env_id0 + (uint64_t)i);
+  st_board(boards, i, b);
+  st_aux(aux, i, a);
+}
+
+__global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux* aux,
+                                                     const uint8_t* actions, int64_t B, uint64_t seed,
+                                                     uint64_t env_id0, uint32_t ctr, float* reward,
+                                                     uint8_t* done, uint8_t* max_l2, uint32_t* status,
+                                                     const uint32_t* draw_pos, const uint32_t* draw_val) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  const int act = actions[i];
+  if (act > 3) {  // rejected, never masked (Game2048_env.py:56-60 would mis-rotate)
+    atomicOr(status, Q2048_STATUS_BAD_ACTION);
+    reward[i] = 0.f; done[i] = 0; max_l2[i] = 0;
+    return;
+  }
+  Board b = ld_board(boards, i);
+  Aux a = ld_aux(aux, i);
+  Draws x;
+  if (draw_pos != nullptr) { x.x2 = draw_pos[i]; x.x3 = draw_val[i]; }  // injected (parity tests)
+  else x = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamStep);
+  const StepOut o = env_step(b, a, act, x.x2, x.x3);
+  st_board(boards, i, b);
+  st_aux(aux, i, a);
+  reward[i] = o.reward; done[i] = o.done; max_l2[i] = o.max_log2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// agent kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_q_choose(const q2048_slot* table, u64 mask,
+                                                     const uint8_t* boards, int64_t B, double eps,
+                                                     uint64_t seed, uint64_t env_id0, uint32_t ctr,
+                                                     uint32_t flags, uint8_t* actions, uint32_t* status,
+                                                     const uint32_t* draw_eps, const uint32_t* draw_act) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  const uint64_t id = env_id0 + (uint64_t)i;
+  const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
+  Draws x;
+  if (draw_eps != nullptr) { x.x0 = draw_eps[i]; x.x1 = draw_act[i]; }  // injected (parity tests)
+  else x = draws(seed, id, ctr, kStreamStep);
+  int act;
+  if (draw_uniform(x.x0) < eps) {  // Agent/main.py:35-36: no table access when exploring
+    act = draw_action(x.x1);
+  } else {
+    Row r;
+    probe_find(table, mask, state_key(ld_board(boards, i), salt, status), r);
+    act = argmax4(r.q0, r.q1, r.q2, r.q3);
+  }
+  actions[i] = (uint8_t)act;
+}
+
+__global__ __launch_bounds__(kBlock) void k_q_lookup(const q2048_slot* table, u64 mask,
+                                                     const uint8_t* boards, int64_t B, uint64_t env_id0,
+                                                     uint32_t flags, float* q_out, uint8_t* found) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(env_id0 + (uint64_t)i) : 0ull;
+  bool ov;
+  u64 key = pack_key(ld_board(boards, i), ov) ^ salt;
+  key = key == 0ull ? 1ull : key;
+  Row r;
+  const int64_t slot = probe_find(table, mask, key, r);
+  reinterpret_cast<float4*>(q_out)[i] = make_float4(r.q0, r.q1, r.q2, r.q3);
+  if (found != nullptr) found[i] = slot >= 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask, const uint8_t* s,
+                                                     const uint8_t* actions, const float* reward,
+                                                     const uint8_t* s2, const uint8_t* done, int64_t B,
+                                                     double lr, double gamma, uint64_t env_id0,
+                                                     uint32_t flags, int64_t* stats_i, uint32_t* status) {
+  __shared__ BlockStats bs;
+  stats_clear(bs);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < B) {
+    const int act = actions[i];
+    bool inserted = false, dropped = false;
+    uint32_t retries = 0;
+    if (act > 3) {
+      atomicOr(status, Q2048_STATUS_BAD_ACTION);
+    } else {
+      const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(env_id0 + (uint64_t)i) : 0ull;
+      const u64 key_s = state_key(ld_board(s, i), salt, status);
+      const u64 key_n = state_key(ld_board(s2, i), salt, status);
+      Row rn;
+      probe_find(table, mask, key_n, rn);                                   // Agent/main.py:41
+      const float max_next = max4(rn.q0, rn.q1, rn.q2, rn.q3);
+      const int64_t slot = probe_insert(table, mask, key_s, inserted);
+      if (slot >= 0) {
+        const float cur = bits_f32(__hip_atomic_load(
+            reinterpret_cast<unsigned int*>(&table[slot].q[act]), __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT));
+        td_update(&table[slot], act, cur, reward[i], max_next, done[i] != 0, lr, gamma, retries);
+      } else {
+        dropped = true;
+        atomicOr(status, Q2048_STATUS_TABLE_FULL);
+      }
+    }
+    const uint32_t n_ins = wave_count(inserted), n_drop = wave_count(dropped);
+    if (retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)retries);
+    const u64 active = __ballot(true);  // the first active lane publishes the wave's ballots
+    if ((u64)(threadIdx.x & 63) == (u64)__ffsll((long long)active) - 1ull) {
+      if (n_ins) atomicAdd(&bs.i[Q2048_ST_INSERTS], (u64)n_ins);
+      if (n_drop) atomicAdd(&bs.i[Q2048_ST_DROPS], (u64)n_drop);
+    }
+  }
+  stats_flush(bs, stats_i, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused rollout: Agent/main.py:91-101 + reset (:81), `steps` times per lane in one launch
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_fused_rollout(
+    uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
+    double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
+    int64_t* stats_i, double* stats_f, uint32_t* status) {
+  __shared__ BlockStats bs;
+  stats_clear(bs);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < B) {
+    const uint64_t id = env_id0 + (uint64_t)i;
+    const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
+    Board b = ld_board(boards, i);
+    Aux a = ld_aux(aux, i);
+    u64 key_s = state_key(b, salt, status);
+    Row q;
+    int64_t slot_s = probe_find(table, mask, key_s, q);
+    // wave-uniform counters (ballots) and rare per-lane ones
+    uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = 0, n_drop = 0, retries = 0;
+    double reward_sum = 0.0;
+
+    for (int t = 0; t < steps; ++t) {
+      const Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
+      bool explored;
+      const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);  // main.py:92
+      const StepOut o = env_step(b, a, act, x.x2, x.x3);                               // :93
+      const u64 key_n = state_key(b, salt, status);                                    // :94
+      Row qn = q;
+      int64_t slot_n = slot_s;
+      if (key_n != key_s) slot_n = probe_find(table, mask, key_n, qn);                 // :41
+      const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
+      bool inserted = false, updated = false;
+      if (slot_s < 0) slot_s = probe_insert(table, mask, key_s, inserted);
+      float nq = 0.f;
+      if (slot_s >= 0) {
+        nq = td_update(&table[slot_s], act, row_get(q, act), o.reward, max_next, o.done != 0, lr,
+                       gamma, retries);                                                // :99
+        updated = true;
+      }
+      n_valid += wave_count(o.valid != 0);
+      n_explore += wave_count(explored);
+      n_insert += wave_count(inserted);
+      n_drop += wave_count(!updated);
+      n_done += wave_count(o.done != 0);
+      reward_sum += (double)o.reward;
+      if (o.done) {                                                                    // :103
+        episode_stats(bs, a, o.max_log2);
+        begin_episode(b, a, seed, id);                                                 // :81
+        key_s = state_key(b, salt, status);
+        slot_s = probe_find(table, mask, key_s, q);
+      } else if (key_n == key_s) {  // invalid move: same state, its row just changed (:100)
+        if (updated) row_set(q, act, nq);
+      } else {
+        key_s = key_n; slot_s = slot_n; q = qn;                                        // :100
+      }
+    }
+    st_board(boards, i, b);
+    st_aux(aux, i, a);
+
+    if (n_drop) atomicOr(status, Q2048_STATUS_TABLE_FULL);
+    if (retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)retries);
+    atomicAdd(&bs.f[Q2048_SF_REWARD], reward_sum);
+    const u64 active = __ballot(true);
+    if ((u64)(threadIdx.x & 63) == (u64)__ffsll((long long)active) - 1ull) {
+      atomicAdd(&bs.i[Q2048_ST_STEPS], (u64)__popcll(active) * (u64)steps);
+      atomicAdd(&bs.i[Q2048_ST_VALID], (u64)n_valid);
+      atomicAdd(&bs.i[Q2048_ST_EXPLORE], (u64)n_explore);
+      atomicAdd(&bs.i[Q2048_ST_EPISODES], (u64)n_done);
+      atomicAdd(&bs.i[Q2048_ST_INSERTS], (u64)n_insert);
+      atomicAdd(&bs.i[Q2048_ST_DROPS], (u64)n_drop);
+    }
+  }
+  stats_flush(bs, stats_i, stats_f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// table utilities
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_table_export(const q2048_slot* table, u64 cap,
+                                                         u64* keys_out, float* q_out, int64_t max_rows,
+                                                         u64* count) {
+  const u64 stride = (u64)gridDim.x * kBlock;
+  for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < cap; i += stride) {
+    const u64 k = table[i].key;
+    if (k == 0ull) continue;
+    const u64 at = atomicAdd(count, 1ull);
+    if (keys_out != nullptr && (int64_t)at < max_rows) {
+      keys_out[at] = k;
+      reinterpret_cast<float4*>(q_out)[at] =
+          make_float4(table[i].q[0], table[i].q[1], table[i].q[2], table[i].q[3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side of the ABI
+// ---------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline unsigned grid_for(int64_t B) { return (unsigned)((B + kBlock - 1) / kBlock); }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? Q2048_OK : Q2048_ERR_LAUNCH; }
+inline int check_batch(int64_t B, int n) {
+  if (n != 4) return Q2048_ERR_UNSUPPORTED;
+  if (B < 0 || B > ((int64_t)1 << 40)) return Q2048_ERR_SIZE;
+  return Q2048_OK;
+}
+inline int check_table(const void* table, int cap_log2) {
+  if (table == nullptr) return Q2048_ERR_NULL;
+  if (cap_log2 < 4 || cap_log2 > 40) return Q2048_ERR_SIZE;
+  if (!aligned16(table)) return Q2048_ERR_ALIGN;
+  return Q2048_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int q2048_abi_version(void) { return Q2048_ABI_VERSION; }
+size_t q2048_sizeof_aux(void) { return sizeof(q2048_aux); }
+size_t q2048_sizeof_slot(void) { return sizeof(q2048_slot); }
+
+const char* q2048_strerror(int code) {
+  switch (code) {
+    case Q2048_OK: return "ok";
+    case Q2048_ERR_NULL: return "a required pointer is NULL";
+    case Q2048_ERR_SIZE: return "size out of range (batch, steps or cap_log2)";
+    case Q2048_ERR_ALIGN: return "boards/aux/table must be 16-byte aligned";
+    case Q2048_ERR_UNSUPPORTED: return "unsupported board side (only n == 4)";
+    case Q2048_ERR_LAUNCH: return "HIP launch failed";
+    case Q2048_ERR_RANGE: return "scalar out of range (eps in [0,1], lr and gamma finite)";
+    default: return "unknown error";
+  }
+}
+
+int q2048_env_init(uint8_t* boards, q2048_aux* aux, int64_t B, int n, uint64_t seed,
+                   uint64_t env_id0, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (boards == nullptr || aux == nullptr) return Q2048_ERR_NULL;
+  if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
+  if (B == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_env_init, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, boards,
+                     aux, B, seed, env_id0);
+  return launch_status();
+}
+
+int q2048_env_reset(uint8_t* boards, q2048_aux* aux, const uint8_t* mask, int64_t B, int n,
+                    uint64_t seed, uint64_t env_id0, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (boards == nullptr || aux == nullptr) return Q2048_ERR_NULL;
+  if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
+  if (B == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_env_reset, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, boards,
+                     aux, mask, B, seed, env_id0);
+  return launch_status();
+}
+
+static int env_step_impl(uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, int n,
+                         uint64_t seed, uint64_t env_id0, uint32_t ctr, float* reward,
+                         uint8_t* done, uint8_t* max_log2, uint32_t* status,
+                         const uint32_t* draw_pos, const uint32_t* draw_val, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (!boards || !aux || !actions || !reward || !done || !max_log2 || !status) return Q2048_ERR_NULL;
+  if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
+  if (B == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_env_step, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, boards,
+                     aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status, draw_pos,
+                     draw_val);
+  return launch_status();
+}
+
+int q2048_env_step(uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, int n,
+                   uint64_t seed, uint64_t env_id0, uint32_t ctr, float* reward, uint8_t* done,
+                   uint8_t* max_log2, uint32_t* status, void* stream) {
+  return env_step_impl(boards, aux, actions, B, n, seed, env_id0, ctr, reward, done, max_log2,
+                       status, nullptr, nullptr, stream);
+}
+
+int q2048_env_step_draws(uint8_t* boards, q2048_aux* aux, const uint8_t* actions,
+                         const uint32_t* draw_pos, const uint32_t* draw_val, int64_t B, int n,
+                         float* reward, uint8_t* done, uint8_t* max_log2, uint32_t* status,
+                         void* stream) {
+  if (!draw_pos || !draw_val) return Q2048_ERR_NULL;
+  return env_step_impl(boards, aux, actions, B, n, 0, 0, 0, reward, done, max_log2, status,
+                       draw_pos, draw_val, stream);
+}
+
+static int q_choose_impl(const q2048_slot* table, int cap_log2, const uint8_t* boards, int64_t B,
+                         int n, double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr,
+                         uint32_t flags, uint8_t* actions, uint32_t* status,
+                         const uint32_t* draw_eps, const uint32_t* draw_act, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (int e = check_table(table, cap_log2)) return e;
+  if (!boards || !actions || !status) return Q2048_ERR_NULL;
+  if (!aligned16(boards)) return Q2048_ERR_ALIGN;
+  if (!(eps >= 0.0 && eps <= 1.0)) return Q2048_ERR_RANGE;
+  if (B == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_q_choose, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
+                     (u64)((1ull << cap_log2) - 1ull), boards, B, eps, seed, env_id0, ctr, flags,
+                     actions, status, draw_eps, draw_act);
+  return launch_status();
+}
+
+int q2048_q_choose(const q2048_slot* table, int cap_log2, const uint8_t* boards, int64_t B, int n,
+                   double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags,
+                   uint8_t* actions, uint32_t* status, void* stream) {
+  return q_choose_impl(table, cap_log2, boards, B, n, eps, seed, env_id0, ctr, flags, actions,
+                       status, nullptr, nullptr, stream);
+}
+
+int q2048_q_choose_draws(const q2048_slot* table, int cap_log2, const uint8_t* boards,
+                         const uint32_t* draw_eps, const uint32_t* draw_act, int64_t B, int n,
+                         double eps, uint64_t env_id0, uint32_t flags, uint8_t* actions,
+                         uint32_t* status, void* stream) {
+  if (!draw_eps || !draw_act) return Q2048_ERR_NULL;
+  return q_choose_impl(table, cap_log2, boards, B, n, eps, 0, env_id0, 0, flags, actions, status,
+                       draw_eps, draw_act, stream);
+}
+
+int q2048_q_update(q2048_slot* table, int cap_log2, const uint8_t* boards_s, const uint8_t* actions,
+                   const float* reward, const uint8_t* boards_s2, const uint8_t* done, int64_t B,
+                   int n, double lr, double gamma, uint64_t env_id0, uint32_t flags,
+                   int64_t* stats_i, uint32_t* status, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (int e = check_table(table, cap_log2)) return e;
+  if (!boards_s || !actions || !reward || !boards_s2 || !done || !status) return Q2048_ERR_NULL;
+  if (!aligned16(boards_s) || !aligned16(boards_s2)) return Q2048_ERR_ALIGN;
+  if (!(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
+  if (B == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_q_update, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
+                     (u64)((1ull << cap_log2) - 1ull), boards_s, actions, reward, boards_s2, done, B,
+                     lr, gamma, env_id0, flags, stats_i, status);
+  return launch_status();
+}
+
+int q2048_q_lookup(const q2048_slot* table, int cap_log2, const uint8_t* boards, int64_t B, int n,
+                   uint64_t env_id0, uint32_t flags, float* q_out, uint8_t* found, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (int e = check_table(table, cap_log2)) return e;
+  if (!boards || !q_out) return Q2048_ERR_NULL;
+  if (!aligned16(boards) || !aligned16(q_out)) return Q2048_ERR_ALIGN;
+  if (B == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_q_lookup, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
+                     (u64)((1ull << cap_log2) - 1ull), boards, B, env_id0, flags, q_out, found);
+  return launch_status();
+}
+
+int q2048_fused_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2, int64_t B,
+                        int n, int64_t steps, double eps, double lr, double gamma, uint64_t seed,
+                        uint64_t env_id0, uint32_t ctr0, uint32_t flags, int64_t* stats_i,
+                        double* stats_f, uint32_t* status, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (int e = check_table(table, cap_log2)) return e;
+  if (!boards || !aux || !status) return Q2048_ERR_NULL;
+  if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
+  if (steps < 0 || steps > (1 << 30)) return Q2048_ERR_SIZE;
+  if (!(eps >= 0.0 && eps <= 1.0) || !(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
+  if (B == 0 || steps == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_fused_rollout, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream,
+                     boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B, (int)steps, eps, lr,
+                     gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status);
+  return launch_status();
+}
+
+int q2048_table_count(const q2048_slot* table, int cap_log2, int64_t* count, void* stream) {
+  return q2048_table_export(table, cap_log2, nullptr, nullptr, 0, count, stream);
+}
+
+int q2048_table_export(const q2048_slot* table, int cap_log2, uint64_t* keys_out, float* q_out,
+                       int64_t max_rows, int64_t* count, void* stream) {
+  if (int e = check_table(table, cap_log2)) return e;
+  if (count == nullptr) return Q2048_ERR_NULL;
+  if ((keys_out == nullptr) != (q_out == nullptr) || max_rows < 0) return Q2048_ERR_SIZE;
+  if (q_out != nullptr && !aligned16(q_out)) return Q2048_ERR_ALIGN;
+  const u64 cap = 1ull << cap_log2;
+  const u64 blocks = (cap + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_table_export, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0,
+                     (hipStream_t)stream, table, cap, reinterpret_cast<u64*>(keys_out), q_out,
+                     max_rows, reinterpret_cast<u64*>(count));
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+"""Multi-GPU sharding of the env batch: one process per GPU, no data-path collective.
+
+The reference runs one env in one process (no distributed code).  Envs are independent, so the
+batch shards embarrassingly: rank r owns a contiguous range of GLOBAL env ids, and because the
+counter RNG is keyed by the global id, every env's trajectory is independent of the world size.
+Each GPU keeps its own Q-table replica.  The only collective is a SUM all-reduce of the
+episode statistics vector (a few hundred bytes, latency-bound) over RCCL (`nccl` backend on
+ROCm) or gloo in the CPU tests."""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+
+
+@dataclass(frozen=True)
+class Shard:
+    rank: int
+    world_size: int
+    env_id0: int     # first global env id of this rank
+    num_envs: int    # envs on this rank
+    total_envs: int
+
+
+def shard_plan(total_envs: int, world_size: int, rank: int, base_env_id: int = 0) -> Shard:
+    """Contiguous split of [base, base + total) over ranks; the first `total % world` ranks
+    take one extra env."""
+    if world_size <= 0 or not 0 <= rank < world_size:
+        raise ValueError(f"bad rank {rank} / world_size {world_size}")
+    if total_envs < world_size:
+        raise ValueError("fewer envs than ranks")
+    q, r = divmod(total_envs, world_size)
+    n = q + (1 if rank < r else 0)
+    start = rank * q + min(rank, r)
+    return Shard(rank, world_size, base_env_id + start, n, total_envs)
+
+
+def weak_shard(envs_per_gpu: int, world_size: int, rank: int, base_env_id: int = 0) -> Shard:
+    """Weak scaling (BASELINE config 4: 8 x 1,048,576 boards): fixed envs per GPU."""
+    return shard_plan(envs_per_gpu * world_size, world_size, rank, base_env_id)
+
+
+def env_from_torchrun() -> tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1 process = 1 GPU)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: str | None = None) -> tuple[int, int, int]:
+    """Joins the job's process group (no-op for a single process).  `nccl` is RCCL on ROCm."""
+    rank, local_rank, world = env_from_torchrun()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def allreduce_stats(stats_i: torch.Tensor, stats_f: torch.Tensor, group=None):
+    """SUM all-reduce of the statistics vectors in place (every entry is additive: counts,
+    sums, histogram bins).  Tensors stay where they are (HBM for nccl, host for gloo)."""
+    if stats_i.numel() != N.NSTAT_I or stats_f.numel() != N.NSTAT_F:
+        raise ValueError("unexpected statistics vector length")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(stats_i, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(stats_f, op=dist.ReduceOp.SUM, group=group)
+    return stats_i, stats_f
+
+
+def max_over_ranks(value: float, device=None, group=None) -> float:
+    """MAX all-reduce of one float (bench timing: the slowest rank defines the step time)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def barrier(group=None) -> None:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)
+
+
+def merge_stats_numpy(parts_i, parts_f):
+    """Host-side reference of the all-reduce (tests)."""
+    return np.sum(np.stack(parts_i), axis=0), np.sum(np.stack(parts_f), axis=0)

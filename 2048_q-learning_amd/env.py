@@ -1,0 +1,192 @@
+"""Batched 2048 environment on MI355X: the host-side mirror of
+QLearningBase/environment/Game2048_env.py (class Game2048_env, :78-205).
+
+`BatchedGame2048Env` keeps the reference's method names (`reset`, `step`, `action_space.n`,
+`score`) over B boards resident in HBM; `Game2048_env` is the one-env adapter that returns
+the reference's Python types so that the loop body of Agent/main.py:91-101 runs unchanged.
+All computation happens in the HIP kernels behind include/q2048.h; torch only owns the device
+memory and the stream."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+class _Discrete:
+    """Stand-in for gymnasium.spaces.Discrete: the reference only reads `.n`
+    (Game2048_env.py:89, Agent/main.py:68)."""
+
+    def __init__(self, n: int):
+        self.n = n
+
+
+def _ptr(t: torch.Tensor | None):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("2048_q-learning_amd runs on MI355X only (device must be 'cuda[:i]'); "
+                           "there is no CPU implementation of the product path")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: the HIP extension cannot run")
+    N.lib()
+    return device
+
+
+class BatchedGame2048Env:
+    """B independent 4x4 boards, one per GPU lane.
+
+    boards  torch.uint8 [B, 16]  log2 tiles, row-major (0 empty, k = tile 2^k)
+    aux     torch.uint8 [B, 16]  q2048_aux records (score, return, previous_max, streak, episode)
+
+    Lane i is global env `env_id0 + i`; its random draws depend only on (seed, global id,
+    step counter), never on B or on how a batch is sharded over GPUs."""
+
+    def __init__(self, num_envs: int, board_size: int = 4, device="cuda", seed: int = 0,
+                 env_id0: int = 0):
+        self.device = _require_gpu(device)
+        if board_size != 4:
+            raise NotImplementedError("board_size 5 is a later round; only 4x4 is implemented")
+        if num_envs <= 0:
+            raise ValueError("num_envs must be positive")
+        self.num_envs, self.board_size = int(num_envs), 4
+        self.seed, self.env_id0 = int(seed), int(env_id0)
+        self.ctr = 0  # global step counter = counter word of the step draws
+        self.action_space = _Discrete(4)                                 # Game2048_env.py:89
+        B = self.num_envs
+        self.boards = torch.empty((B, 16), dtype=torch.uint8, device=self.device)
+        self.aux = torch.empty((B, 16), dtype=torch.uint8, device=self.device)
+        self._reward = torch.empty(B, dtype=torch.float32, device=self.device)
+        self._done = torch.empty(B, dtype=torch.uint8, device=self.device)
+        self._max = torch.empty(B, dtype=torch.uint8, device=self.device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        N.check(N.lib().q2048_env_init(_ptr(self.boards), _ptr(self.aux), B, 4, self.seed,
+                                       self.env_id0, _stream(self.device)), "env_init")
+
+    # -- reference surface ---------------------------------------------------------------
+    def reset(self, mask: torch.Tensor | None = None) -> torch.Tensor:
+        """Game2048_env.reset (:187-191) for the lanes where mask != 0 (all when None)."""
+        if mask is not None:
+            mask = self._as_u8(mask, "mask")
+        N.check(N.lib().q2048_env_reset(_ptr(self.boards), _ptr(self.aux), _ptr(mask),
+                                        self.num_envs, 4, self.seed, self.env_id0,
+                                        _stream(self.device)), "env_reset")
+        return self.boards
+
+    def step(self, actions: torch.Tensor):
+        """Game2048_env.step (:97-129): returns (boards, reward[B] f32, done[B] bool,
+        max_tile[B] int32 raw tile value, the reference's `info`)."""
+        actions = self._as_u8(actions, "actions")
+        N.check(N.lib().q2048_env_step(
+            _ptr(self.boards), _ptr(self.aux), _ptr(actions), self.num_envs, 4, self.seed,
+            self.env_id0, self.ctr & 0xFFFFFFFF, _ptr(self._reward), _ptr(self._done),
+            _ptr(self._max), _ptr(self.status), _stream(self.device)), "env_step")
+        self.ctr += 1
+        max_tile = torch.bitwise_left_shift(torch.ones_like(self._max, dtype=torch.int32),
+                                            self._max.to(torch.int32))
+        return self.boards, self._reward, self._done.bool(), max_tile
+
+    @property
+    def score(self) -> torch.Tensor:
+        """env.score (:84) per lane."""
+        return self.aux.view(torch.int32)[:, 0]
+
+    @property
+    def max_log2(self) -> torch.Tensor:
+        return self._max
+
+    # -- helpers --------------------------------------------------------------------------
+    def aux_fields(self) -> dict:
+        """Host copy of the aux records as numpy fields (tests / logging)."""
+        a = self.aux.cpu().numpy().view(AUX_DTYPE).reshape(-1)
+        return {k: a[k].copy() for k in AUX_DTYPE.names}
+
+    def check_status(self) -> int:
+        """Synchronising read of the device status word; raises on a rejected action."""
+        s = int(self.status.item())
+        if s & N.STATUS_BAD_ACTION:
+            self.status.zero_()
+            raise ValueError("an action outside 0..3 was passed to step() (lane left untouched)")
+        return s
+
+    def _as_u8(self, t, name: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(t)
+        if t.dtype == torch.bool:
+            t = t.to(torch.uint8)
+        if t.dtype != torch.uint8:
+            if t.numel() and (int(t.min()) < 0 or int(t.max()) > 255):
+                raise ValueError(f"{name} out of range")
+            t = t.to(torch.uint8)
+        t = t.to(self.device).contiguous()
+        if t.shape != (self.num_envs,):
+            raise ValueError(f"{name} must have shape ({self.num_envs},), got {tuple(t.shape)}")
+        return t
+
+
+AUX_DTYPE = np.dtype([("score", "<i4"), ("ep_return", "<f4"), ("prev_max", "u1"),
+                      ("cons_action", "u1"), ("cons_count", "<u2"), ("episode", "<u4")])
+
+
+def boards_to_raw(boards_log2) -> np.ndarray:
+    """uint8 log2 boards [...,16] -> np.int64 raw tile values [...,4,4] (reference layout)."""
+    b = np.asarray(boards_log2, dtype=np.int64)
+    return np.where(b > 0, np.left_shift(1, b), 0).reshape(b.shape[:-1] + (4, 4))
+
+
+def raw_to_boards(raw) -> np.ndarray:
+    """Reference boards (raw tile values, any nesting of 4x4) -> uint8 log2 [...,16]."""
+    r = np.asarray(raw, dtype=np.int64)
+    r = r.reshape(r.shape[:-2] + (16,)) if r.shape[-2:] == (4, 4) else r
+    out = np.zeros(r.shape, dtype=np.uint8)
+    nz = r > 0
+    lg = np.zeros(r.shape, dtype=np.int64)
+    lg[nz] = np.round(np.log2(r[nz])).astype(np.int64)
+    if np.any(np.left_shift(1, lg[nz]) != r[nz]):
+        raise ValueError("board holds a value that is not a power of two")
+    out[nz] = lg[nz]
+    return out
+
+
+class _Game:
+    """`env.game.board` of the reference (Agent/main.py:85-86)."""
+
+    def __init__(self, env: "Game2048_env"):
+        self._env = env
+
+    @property
+    def board(self) -> np.ndarray:
+        return boards_to_raw(self._env._b.boards.cpu().numpy())[0]
+
+
+class Game2048_env:
+    """One env with the reference's exact surface and Python types
+    (Game2048_env.py:78-205): reset() -> int64[4,4], step(a) -> (board, float, bool, int)."""
+
+    def __init__(self, device="cuda", seed: int = 0, env_id: int = 0):
+        self._b = BatchedGame2048Env(1, 4, device, seed, env_id)
+        self.action_space = self._b.action_space
+        self.game = _Game(self)
+
+    def reset(self) -> np.ndarray:
+        self._b.reset()
+        return self.game.board
+
+    def step(self, action: int):
+        if not 0 <= int(action) <= 3:
+            raise ValueError(f"action {action} outside 0..3")
+        act = torch.tensor([int(action)], dtype=torch.uint8, device=self._b.device)
+        _, r, d, m = self._b.step(act)
+        return self.game.board, float(r.item()), bool(d.item()), int(m.item())
+
+    @property
+    def score(self) -> int:
+        return int(self._b.score.item())

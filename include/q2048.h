@@ -1,0 +1,180 @@
+/*
+ * q2048.h -- C ABI of libq2048_hip.so: the MI355X (gfx950) hot path of the batched 2048
+ * tabular Q-learning loop.
+ *
+ * This is the drop-in boundary for the path of Rocco9999/2048_Q-Learning named by
+ * BASELINE.json: QLearningBase/environment/Game2048_env.py (Game2048_env.step/reset) and
+ * QLearningBase/Agent/main.py (QLearningAgent.choose_action/update_q_value).  The reference is
+ * pure Python and has no FFI; these are the entry points a binding for that path needs
+ * (INTEGRATION.md shows the ctypes stub).  Every function below names the reference
+ * interface it replaces.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  Every data pointer is a DEVICE pointer (HIP); the caller
+ *     owns all memory (the library never allocates); `stream` is a hipStream_t (NULL = default
+ *     stream).  All calls are asynchronous and stream-ordered: no host synchronisation inside.
+ *   - boards   uint8_t[B][16]: 4x4 board, row-major, log2 tiles (0 empty, k = tile 2^k), the
+ *              device image of the reference's np.int64[4,4] raw-value board
+ *              (Game2048_env.py:12).  16-byte aligned.
+ *   - aux      q2048_aux[B]: per-env state that Game2048_env keeps in Python attributes
+ *              (Game2048_env.py:81-95).  16-byte aligned.
+ *   - table    q2048_slot[1 << cap_log2]: open-addressed hash Q-table, the device form of
+ *              `defaultdict(lambda: np.zeros(4))` (Agent/main.py:16).  Zero-filled = empty.
+ *   - RNG      counter based: draws = Philox4x32-10(key = seed, counter = (global env id,
+ *              step counter ctr, stream)); lane i has global env id env_id0 + i, so results do
+ *              not depend on how a batch is sharded over GPUs.
+ *   - return   0 on success, a negative Q2048_ERR_* otherwise (argument errors are detected
+ *              on the host before anything is launched).  Data-dependent conditions are
+ *              reported through the device `status` word (Q2048_STATUS_* bits, OR-ed).
+ *   - n        board side.  This round implements n == 4; other values return
+ *              Q2048_ERR_UNSUPPORTED.
+ */
+#ifndef Q2048_H
+#define Q2048_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Q2048_ABI_VERSION 1
+
+/* return codes */
+#define Q2048_OK 0
+#define Q2048_ERR_NULL (-1)        /* a required pointer is NULL */
+#define Q2048_ERR_SIZE (-2)        /* negative batch / steps, bad cap_log2 */
+#define Q2048_ERR_ALIGN (-3)       /* boards / aux / table not 16-byte aligned */
+#define Q2048_ERR_UNSUPPORTED (-4) /* board side other than 4 */
+#define Q2048_ERR_LAUNCH (-5)      /* the HIP runtime refused the launch */
+#define Q2048_ERR_RANGE (-6)       /* a scalar is outside its domain (eps, lr, gamma) */
+
+/* bits of the device status word */
+#define Q2048_STATUS_BAD_ACTION 1u    /* an action outside 0..3 was passed (lane left untouched) */
+#define Q2048_STATUS_TILE_OVERFLOW 2u /* a tile above 2^15 does not fit the 64-bit state key */
+#define Q2048_STATUS_TABLE_FULL 4u    /* an update found no slot within the probe limit (dropped) */
+
+/* flags */
+#define Q2048_FLAG_INDEPENDENT 1u /* every env owns private Q rows (key salted by its global id) */
+
+/* per-env state, Game2048_env.__init__ (Game2048_env.py:81-95) + episode bookkeeping */
+typedef struct q2048_aux {
+  int32_t score;       /* env.score (:84); zeroed by reset (:190) */
+  float ep_return;     /* running total_reward of Agent/main.py:84,101 */
+  uint8_t prev_max;    /* log2(env.previous_max) (:87); NOT reset (:187-191) */
+  uint8_t cons_action; /* env.consecutive_action (:92), 0xFF = None; NOT reset */
+  uint16_t cons_count; /* env.consecutive_count (:93), saturates at 60000; NOT reset */
+  uint32_t episode;    /* number of resets so far (counter of the reset draws) */
+} q2048_aux;
+
+/* one row of the Q-table: q_table[state] -> 4 floats (Agent/main.py:16) */
+typedef struct q2048_slot {
+  uint64_t key;      /* 16 log2 nibbles, cell 0 in the low nibble; 0 = empty slot */
+  float q[4];        /* Q(s, a), a = 0 left, 1 up, 2 right, 3 down */
+  uint64_t reserved; /* keeps rows 32-byte aligned (never straddles a 64-byte line) */
+} q2048_slot;
+
+/* indices of the statistics vectors (device int64[Q2048_NSTAT_I], double[Q2048_NSTAT_F]);
+ * kernels ADD to them, the caller zeroes them */
+enum {
+  Q2048_ST_STEPS = 0,    /* env steps executed */
+  Q2048_ST_EPISODES = 1, /* episodes finished */
+  Q2048_ST_VALID = 2,    /* board-changing moves */
+  Q2048_ST_SCORE = 3,    /* sum of env.score over finished episodes */
+  Q2048_ST_INSERTS = 4,  /* Q rows created */
+  Q2048_ST_DROPS = 5,    /* updates dropped (probe limit) */
+  Q2048_ST_EXPLORE = 6,  /* epsilon branch taken */
+  Q2048_ST_CAS_RETRY = 7,/* TD compare-and-swap retries (same (s,a) updated concurrently) */
+  Q2048_ST_HIST0 = 8,    /* max-tile histogram of finished episodes, log2 0..23 */
+  Q2048_NSTAT_I = 32
+};
+enum { Q2048_SF_RETURN = 0, Q2048_SF_RETURN_SQ = 1, Q2048_SF_REWARD = 2, Q2048_NSTAT_F = 4 };
+
+int q2048_abi_version(void);
+const char *q2048_strerror(int code);
+size_t q2048_sizeof_aux(void);  /* 16 */
+size_t q2048_sizeof_slot(void); /* 32 */
+
+/* Game2048_env() constructor for B envs (Game2048_env.py:81-95 -> Game2048.__init__ :11-14):
+ * empty board + two spawns from the reset draws of episode 0, aux = initial values. */
+int q2048_env_init(uint8_t *boards, q2048_aux *aux, int64_t B, int n, uint64_t seed,
+                   uint64_t env_id0, void *stream);
+
+/* Game2048_env.reset() (Game2048_env.py:187-191) for the lanes with mask[i] != 0 (all lanes
+ * when mask == NULL): new board with two spawns, score = 0; previous_max and the
+ * consecutive-action state persist, as in the reference. */
+int q2048_env_reset(uint8_t *boards, q2048_aux *aux, const uint8_t *mask, int64_t B, int n,
+                    uint64_t seed, uint64_t env_id0, void *stream);
+
+/* Game2048_env.step(action) (Game2048_env.py:97-129) for B envs: move (:51-63), game-over
+ * probe (:65-75), shaped reward (:136-184, :197-205), stall rule (:110-127).
+ * Outputs per lane: reward (float32 of the reference's float), done, max tile as log2
+ * (reference `info` = 2^max_log2).  An action outside 0..3 leaves its lane untouched and
+ * sets Q2048_STATUS_BAD_ACTION (the reference would silently mis-rotate, :56-60). */
+int q2048_env_step(uint8_t *boards, q2048_aux *aux, const uint8_t *actions, int64_t B, int n,
+                   uint64_t seed, uint64_t env_id0, uint32_t ctr, float *reward, uint8_t *done,
+                   uint8_t *max_log2, uint32_t *status, void *stream);
+
+/* q2048_env_step with the two spawn decisions' raw draws given per lane instead of derived from
+ * (seed, id, ctr): draw_pos replaces np.random.randint(0, n_empty) (Game2048_env.py:19),
+ * draw_val replaces np.random.random() < 0.9 (:20).  Draw injection is how parity with the
+ * reference is pinned (tests/golden); training uses q2048_env_step. */
+int q2048_env_step_draws(uint8_t *boards, q2048_aux *aux, const uint8_t *actions,
+                         const uint32_t *draw_pos, const uint32_t *draw_val, int64_t B, int n,
+                         float *reward, uint8_t *done, uint8_t *max_log2, uint32_t *status,
+                         void *stream);
+
+/* QLearningAgent.choose_action(state) (Agent/main.py:34-38) for B states: epsilon test and
+ * random action from the step draws, else first-maximum argmax of the row (zeros if absent;
+ * a lookup never inserts -- value-equivalent to the defaultdict). */
+int q2048_q_choose(const q2048_slot *table, int cap_log2, const uint8_t *boards, int64_t B,
+                   int n, double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr,
+                   uint32_t flags, uint8_t *actions, uint32_t *status, void *stream);
+
+/* q2048_q_choose with injected draws: draw_eps replaces random.random() (Agent/main.py:35),
+ * draw_act replaces random.randint(0, 3) (:36). */
+int q2048_q_choose_draws(const q2048_slot *table, int cap_log2, const uint8_t *boards,
+                         const uint32_t *draw_eps, const uint32_t *draw_act, int64_t B, int n,
+                         double eps, uint64_t env_id0, uint32_t flags, uint8_t *actions,
+                         uint32_t *status, void *stream);
+
+/* QLearningAgent.update_q_value(state, action, reward, next_state, done)
+ * (Agent/main.py:40-43) for B transitions.  Each lane applies the reference update to the
+ * CURRENT value of Q[s][a] with a compare-and-swap loop, so concurrent updates of one entry
+ * serialise (none is lost or summed); rows are created on first update. */
+int q2048_q_update(q2048_slot *table, int cap_log2, const uint8_t *boards_s,
+                   const uint8_t *actions, const float *reward, const uint8_t *boards_s2,
+                   const uint8_t *done, int64_t B, int n, double lr, double gamma,
+                   uint64_t env_id0, uint32_t flags, int64_t *stats_i, uint32_t *status,
+                   void *stream);
+
+/* agent.q_table[state] (Agent/main.py:16,96) for B states: q_out[B][4] (zeros if absent),
+ * found[B] (may be NULL). */
+int q2048_q_lookup(const q2048_slot *table, int cap_log2, const uint8_t *boards, int64_t B,
+                   int n, uint64_t env_id0, uint32_t flags, float *q_out, uint8_t *found,
+                   void *stream);
+
+/* The loop body of Agent/main.py:91-101 + the reset of :81, `steps` times for B envs in ONE
+ * launch: choose -> step -> update -> accumulate -> (on done) statistics and reset.  Boards,
+ * aux and the Q row of the current state stay in registers between steps.  Step t uses the
+ * draws of counter ctr0 + t.  Bit-identical to calling q_choose / env_step / q_update /
+ * env_reset(done) `steps` times whenever no two lanes share a state. */
+int q2048_fused_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2,
+                        int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
+                        uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
+                        int64_t *stats_i, double *stats_f, uint32_t *status, void *stream);
+
+/* len(agent.q_table): adds the number of occupied slots to *count (device int64). */
+int q2048_table_count(const q2048_slot *table, int cap_log2, int64_t *count, void *stream);
+
+/* Export occupied rows (for conversion to the reference's dict{state -> 4 floats},
+ * Agent/main.py:16): writes up to max_rows (key, q[4]) pairs in unspecified order and adds the
+ * number of occupied slots to *count (rows beyond max_rows are counted, not written). */
+int q2048_table_export(const q2048_slot *table, int cap_log2, uint64_t *keys_out, float *q_out,
+                       int64_t max_rows, int64_t *count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Q2048_H */

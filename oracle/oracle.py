@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
         "orc_agent_new": (vp, [C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
                                C.c_double, C.c_int]),
         "orc_agent_free": (None, [vp]),
+        "orc_agent_reserve": (None, [vp, C.c_int64]),
         "orc_agent_choose": (C.c_int, [vp, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]),
         "orc_agent_update": (None, [vp, u8p, C.c_int, C.c_double, u8p, C.c_int]),
         "orc_agent_decay": (None, [vp, C.c_double]),
@@ -262,6 +263,9 @@ class Agent:
     @epsilon.setter
     def epsilon(self, v: float):
         self._view().epsilon = float(v)
+
+    def reserve(self, rows: int):
+        lib().orc_agent_reserve(self._h, int(rows))
 
     def _key(self, board):
         b = np.zeros(MAXCELLS, dtype=np.uint8)
