@@ -13,13 +13,13 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_PKG, "..", "include"))
-LIB_PATH = os.path.join(CSRC, "libq2048_hip.so")
+LIB_PATH = os.environ.get("Q2048_LIB_PATH") or os.path.join(CSRC, "libq2048_hip.so")  # override: experiments
 SOURCES = ["q2048_kernels.hip"]
 DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_luts.inc"]
 
 OK = 0
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
-FLAG_INDEPENDENT = 1
+FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
 ST_HIST0, NSTAT_I = 8, 32
 SF_RETURN, SF_RETURN_SQ, SF_REWARD, NSTAT_F = 0, 1, 2, 4

@@ -8,6 +8,8 @@ throughput entry point (whole loop body of Agent/main.py:91-101 in one launch).
 `QLearningAgent` is the one-state adapter with the reference's Python types."""
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -48,11 +50,11 @@ class _QTableView:
     values; returns the 4 Q-values as float64 (zeros when the state was never updated)."""
 
     def __init__(self, agent: "BatchedQLearningAgent"):
-        self._a = agent
+        self._a = weakref.proxy(agent)  # no reference cycle: the table frees with the agent
 
     def __getitem__(self, state) -> np.ndarray:
         b = torch.from_numpy(raw_to_boards(np.asarray(state).reshape(1, 4, 4))).to(self._a.device)
-        return self._a.q_values(b, env_id0=self._a.env_id0)[0].double().cpu().numpy()
+        return self._a.q_values(b, env_id=self._a.env_id0)[0].double().cpu().numpy()
 
     def __len__(self) -> int:
         return self._a.table_size()
@@ -66,11 +68,15 @@ class BatchedQLearningAgent:
                     update finds no free slot within the probe limit it is dropped and counted
                     (stats['drops'], status TABLE_FULL) -- never an exception.
     independent     every env owns private rows (keys salted with its global id): B independent
-                    learners in one table, exactly B reference agents side by side."""
+                    learners in one table, exactly B reference agents side by side.
+    strict_td       update Q[s][a] with a compare-and-swap loop (concurrent updates of one entry
+                    serialise) instead of one store (last writer wins).  Same result whenever
+                    no two lanes share (s, a); several times slower when many lanes do."""
 
     def __init__(self, total_epochs, action_space=4, learning_rate=0.1, discount_factor=0.9,
                  exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 24,
-                 device="cuda", seed: int = 0, env_id0: int = 0, independent: bool = False):
+                 device="cuda", seed: int = 0, env_id0: int = 0, independent: bool = False,
+                 strict_td: bool = False):
         self.device = _require_gpu(device)
         if action_space != 4:
             raise ValueError("the 2048 action space has 4 actions")
@@ -83,7 +89,8 @@ class BatchedQLearningAgent:
         self.total_epochs = total_epochs
         self.capacity_log2 = int(capacity_log2)
         self.seed, self.env_id0 = int(seed), int(env_id0)
-        self.flags = N.FLAG_INDEPENDENT if independent else 0
+        self.flags = (N.FLAG_INDEPENDENT if independent else 0) | (N.FLAG_TD_CAS if strict_td else 0)
+        self.experiment_bits = 0  # unstable tuning bits OR-ed into fused_rollout's flags
         self.ctr = 0  # choose_action calls so far = counter word of the step draws
         self.table = torch.zeros((1 << self.capacity_log2, N.SIZEOF_SLOT), dtype=torch.uint8,
                                  device=self.device)
@@ -132,16 +139,19 @@ class BatchedQLearningAgent:
             _ptr(next_boards), _ptr(done), B, 4, float(self.lr), float(self.gamma), self.env_id0,
             self.flags, _ptr(self.stats_i), _ptr(self.status), _stream(self.device)), "q_update")
 
-    def q_values(self, boards: torch.Tensor, env_id0: int | None = None,
+    def q_values(self, boards: torch.Tensor, env_id: int | None = None,
                  return_found: bool = False):
-        """q_table[state] for B states -> float32 [B, 4] (zeros where absent)."""
+        """q_table[state] for B states -> float32 [B, 4] (zeros where absent).  In independent
+        mode board i is looked up in the rows of env `env_id0 + i`, or, when `env_id` is given,
+        every board in the rows of that one env."""
         boards = self._boards(boards)
         B = boards.shape[0]
         q = torch.empty((B, 4), dtype=torch.float32, device=self.device)
         found = torch.empty(B, dtype=torch.uint8, device=self.device) if return_found else None
+        flags = self.flags | (N.FLAG_SINGLE_ENV if env_id is not None else 0)
         N.check(N.lib().q2048_q_lookup(
             _ptr(self.table), self.capacity_log2, _ptr(boards), B, 4,
-            self.env_id0 if env_id0 is None else int(env_id0), self.flags, _ptr(q), _ptr(found),
+            self.env_id0 if env_id is None else int(env_id), flags, _ptr(q), _ptr(found),
             _stream(self.device)), "q_lookup")
         return (q, found.bool()) if return_found else q
 
@@ -159,8 +169,9 @@ class BatchedQLearningAgent:
         N.check(N.lib().q2048_fused_rollout(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
             4, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
-            self.env_id0, self.ctr & 0xFFFFFFFF, self.flags, _ptr(self.stats_i),
-            _ptr(self.stats_f), _ptr(self.status), _stream(self.device)), "fused_rollout")
+            self.env_id0, self.ctr & 0xFFFFFFFF, self.flags | self.experiment_bits,
+            _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status), _stream(self.device)),
+            "fused_rollout")
         env.ctr += int(steps)
         self.ctr += int(steps)
 

@@ -72,44 +72,66 @@ __device__ __forceinline__ void row_set(Row& r, int a, float v) {
   r.q2 = a == 2 ? v : r.q2; r.q3 = a == 3 ? v : r.q3;
 }
 
-// Lookup without insertion.  Returns the slot index, or -1 when the key is absent (row = 0).
+// Lookup without insertion.  Returns the slot index (>= 0) when the key is present; otherwise
+// ~h (< 0) where h is the empty slot that ended the probe -- the place an insert of this key
+// would claim -- or kNoSlot when the probe limit was hit.
+constexpr int64_t kNoSlot = INT64_MIN;
 __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask, u64 key, Row& row) {
   u64 i = mix64(key) & mask;
   row = Row{0.f, 0.f, 0.f, 0.f};
   for (int p = 0; p < kMaxProbe; ++p) {
     const u64 k = ld_key(&table[i]);
     if (k == key) { row = ld_row(&table[i]); return (int64_t)i; }
-    if (k == 0ull) return -1;
+    if (k == 0ull) return ~(int64_t)i;
     i = (i + 1ull) & mask;
   }
-  return -1;
+  return kNoSlot;
 }
 
-// Find-or-create.  Returns the slot index or -1 (probe limit: the caller drops the update).
-__device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, u64 key, bool& inserted) {
-  u64 i = mix64(key) & mask;
+// Find-or-create starting at slot `start` (the hint of a failed probe_find, or the home slot).
+// The first access is the claiming compare-and-swap itself: the slot was empty a moment ago.
+// Returns the slot index or kNoSlot (probe limit: the caller drops the update).
+__device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, u64 key, u64 start,
+                                                bool& inserted) {
+  u64 i = start & mask;
   inserted = false;
+  u64 k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key);
+  if (k == 0ull) { inserted = true; return (int64_t)i; }
   for (int p = 0; p < kMaxProbe; ++p) {
-    u64 k = ld_key(&table[i]);
+    if (k == key) return (int64_t)i;
+    i = (i + 1ull) & mask;
+    k = ld_key(&table[i]);
     if (k == 0ull) {
       k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key);
       if (k == 0ull) { inserted = true; return (int64_t)i; }
     }
-    if (k == key) return (int64_t)i;
-    i = (i + 1ull) & mask;
   }
-  return -1;
+  return kNoSlot;
 }
 
 // update_q_value on one entry (Agent/main.py:43) against its CURRENT value.  `guess` is the
-// value this lane last saw; a failed compare-and-swap returns the live value and the update is
-// recomputed from it, so concurrent updates of one (s, a) serialise in some order.
+// value this lane last saw.  Write modes:
+//   STORE (default)  one 4-byte store of the new value: when several lanes update the same
+//          (s, a) at the same time the last writer wins (never a torn value).
+//   CAS (Q2048_FLAG_TD_CAS)  compare-and-swap loop: a failed swap returns the live value and
+//          the update is recomputed from it, so concurrent updates of one (s, a) serialise.
+//   The other modes are measurement variants selected by experiment bits 8..11 of flags.
+enum : uint32_t { kTdStorePlain = 0, kTdCas = 1, kTdStoreSc1 = 2, kTdStoreNt = 3, kTdNone = 4,
+                  kTdAdd = 6 };
 __device__ __forceinline__ float td_update(q2048_slot* slot, int a, float guess, float reward,
                                            float max_next, bool done, double lr, double gamma,
-                                           uint32_t& retries) {
+                                           uint32_t& retries, uint32_t mode) {
   unsigned int* addr = reinterpret_cast<unsigned int*>(&slot->q[a]);
   unsigned int expect = f32_bits(guess);
   float nq = td_value(guess, reward, max_next, done, lr, gamma);
+  if (mode == kTdStoreSc1) {
+    __hip_atomic_store(addr, f32_bits(nq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return nq;
+  }
+  if (mode == kTdStorePlain) { *addr = f32_bits(nq); return nq; }
+  if (mode == kTdStoreNt) { __builtin_nontemporal_store(f32_bits(nq), addr); return nq; }
+  if (mode == kTdNone) return nq;
+  if (mode == kTdAdd) { atomicAdd(&slot->q[a], nq - guess); return nq; }
   for (int it = 0; it < kMaxCas; ++it) {
     const unsigned int prev = atomicCAS(addr, expect, f32_bits(nq));
     if (prev == expect) return nq;
@@ -238,7 +260,8 @@ __global__ __launch_bounds__(kBlock) void k_q_lookup(const q2048_slot* table, u6
                                                      uint32_t flags, float* q_out, uint8_t* found) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= B) return;
-  const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(env_id0 + (uint64_t)i) : 0ull;
+  const uint64_t id = (flags & Q2048_FLAG_SINGLE_ENV) ? env_id0 : env_id0 + (uint64_t)i;
+  const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
   bool ov;
   u64 key = pack_key(ld_board(boards, i), ov) ^ salt;
   key = key == 0ull ? 1ull : key;
@@ -246,6 +269,31 @@ __global__ __launch_bounds__(kBlock) void k_q_lookup(const q2048_slot* table, u6
   const int64_t slot = probe_find(table, mask, key, r);
   reinterpret_cast<float4*>(q_out)[i] = make_float4(r.q0, r.q1, r.q2, r.q3);
   if (found != nullptr) found[i] = slot >= 0;
+}
+
+// A row claim in flight: the compare-and-swap was issued, its result is consumed later, so the
+// round trip hides behind the next step's arithmetic.
+struct Claim { u64 ret; u64 at; bool active; };
+
+__device__ __forceinline__ void claim_issue(q2048_slot* table, int64_t slot, u64 key, Claim& c) {
+  c.active = slot < 0 && slot != kNoSlot;
+  if (c.active) {
+    c.at = (u64)~slot;
+    c.ret = atomicCAS(reinterpret_cast<u64*>(&table[c.at].key), 0ull, key);
+  }
+}
+__device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, u64 key, Claim& c,
+                                                 int64_t slot, bool& inserted) {
+  if (!c.active) return slot;
+  c.active = false;
+  if (c.ret == 0ull) { inserted = true; return (int64_t)c.at; }
+  if (c.ret == key) return (int64_t)c.at;
+  return probe_insert(table, mask, key, c.at + 1ull, inserted);  // another key took the slot
+}
+
+__device__ __forceinline__ uint32_t td_mode_of(uint32_t flags) {
+  const uint32_t x = (flags >> 8) & 15u;  // experiment bits (not ABI)
+  return x ? x : ((flags & Q2048_FLAG_TD_CAS) ? kTdCas : kTdStorePlain);
 }
 
 __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask, const uint8_t* s,
@@ -258,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < B) {
     const int act = actions[i];
-    bool inserted = false, dropped = false;
+    bool ins_n = false, ins_s = false, dropped = false;
     uint32_t retries = 0;
     if (act > 3) {
       atomicOr(status, Q2048_STATUS_BAD_ACTION);
@@ -266,21 +314,24 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
       const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(env_id0 + (uint64_t)i) : 0ull;
       const u64 key_s = state_key(ld_board(s, i), salt, status);
       const u64 key_n = state_key(ld_board(s2, i), salt, status);
+      // q_table[next_state] (Agent/main.py:41): the defaultdict creates the row, so do we
       Row rn;
-      probe_find(table, mask, key_n, rn);                                   // Agent/main.py:41
+      const int64_t slot_n = probe_find(table, mask, key_n, rn);
+      if (slot_n < 0 && slot_n != kNoSlot) probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
       const float max_next = max4(rn.q0, rn.q1, rn.q2, rn.q3);
-      const int64_t slot = probe_insert(table, mask, key_s, inserted);
+      // q_table[state][action] (:43)
+      Row rs;
+      int64_t slot = probe_find(table, mask, key_s, rs);
+      if (slot < 0 && slot != kNoSlot) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
       if (slot >= 0) {
-        const float cur = bits_f32(__hip_atomic_load(
-            reinterpret_cast<unsigned int*>(&table[slot].q[act]), __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT));
-        td_update(&table[slot], act, cur, reward[i], max_next, done[i] != 0, lr, gamma, retries);
+        td_update(&table[slot], act, row_get(rs, act), reward[i], max_next, done[i] != 0, lr, gamma,
+                  retries, td_mode_of(flags));
       } else {
         dropped = true;
         atomicOr(status, Q2048_STATUS_TABLE_FULL);
       }
     }
-    const uint32_t n_ins = wave_count(inserted), n_drop = wave_count(dropped);
+    const uint32_t n_ins = wave_count(ins_n) + wave_count(ins_s), n_drop = wave_count(dropped);
     if (retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)retries);
     const u64 active = __ballot(true);  // the first active lane publishes the wave's ballots
     if ((u64)(threadIdx.x & 63) == (u64)__ffsll((long long)active) - 1ull) {
@@ -292,7 +343,14 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
 }
 
 // ---------------------------------------------------------------------------------------------
-// fused rollout: Agent/main.py:91-101 + reset (:81), `steps` times per lane in one launch
+// fused rollout: Agent/main.py:91-101 + reset (:81), `steps` times per lane in one launch.
+//
+// Per step and lane the table sees: one probe of the next state (a read), at most one row claim
+// (compare-and-swap on the key word, only for a state reached for the first time) and one
+// 4-byte write of Q[s][a].  The claim of s' is issued as soon as the probe finds it absent and
+// consumed one step later, when s' has become s: its round trip overlaps the next step's
+// arithmetic.  Rows therefore appear exactly when the reference's defaultdict creates them
+// (q_table[next_state] / q_table[state] in update_q_value, Agent/main.py:41-43).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_fused_rollout(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
@@ -304,11 +362,15 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
   if (i < B) {
     const uint64_t id = env_id0 + (uint64_t)i;
     const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
+    const uint32_t td_mode = td_mode_of(flags);
+    // experiment bits (not ABI): 12 no row creation, 13 no next-state probe
+    const bool x_noclaim = (flags >> 12) & 1u, x_noprobe = (flags >> 13) & 1u;
     Board b = ld_board(boards, i);
     Aux a = ld_aux(aux, i);
     u64 key_s = state_key(b, salt, status);
     Row q;
     int64_t slot_s = probe_find(table, mask, key_s, q);
+    Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
     uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = 0, n_drop = 0, retries = 0;
     double reward_sum = 0.0;
@@ -319,35 +381,50 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
       const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);  // main.py:92
       const StepOut o = env_step(b, a, act, x.x2, x.x3);                               // :93
       const u64 key_n = state_key(b, salt, status);                                    // :94
+      const bool same = key_n == key_s;
+      // the row of s: claimed one step ago (in flight since), or now if s opened the episode/launch
+      bool ins_s = false, ins_n = false;
+      slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_s);
+      if (slot_s < 0 && slot_s != kNoSlot && !x_noclaim)
+        slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
+      // q_table[next_state] (:41)
       Row qn = q;
       int64_t slot_n = slot_s;
-      if (key_n != key_s) slot_n = probe_find(table, mask, key_n, qn);                 // :41
-      const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
-      bool inserted = false, updated = false;
-      if (slot_s < 0) slot_s = probe_insert(table, mask, key_s, inserted);
-      float nq = 0.f;
-      if (slot_s >= 0) {
-        nq = td_update(&table[slot_s], act, row_get(q, act), o.reward, max_next, o.done != 0, lr,
-                       gamma, retries);                                                // :99
-        updated = true;
+      if (!same) {
+        if (x_noprobe) { qn = Row{0.f, 0.f, 0.f, 0.f}; slot_n = ~(int64_t)(mix64(key_n) & mask); }
+        else slot_n = probe_find(table, mask, key_n, qn);
       }
-      n_valid += wave_count(o.valid != 0);
-      n_explore += wave_count(explored);
-      n_insert += wave_count(inserted);
-      n_drop += wave_count(!updated);
-      n_done += wave_count(o.done != 0);
-      reward_sum += (double)o.reward;
+      const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
+      float nq = 0.f;
+      const bool updated = slot_s >= 0;
+      if (updated)
+        nq = td_update(&table[slot_s], act, row_get(q, act), o.reward, max_next, o.done != 0, lr,
+                       gamma, retries, td_mode);                                       // :43, :99
       if (o.done) {                                                                    // :103
+        // the terminal state's row exists in the reference too (looked up at :41)
+        if (!same && slot_n < 0 && slot_n != kNoSlot && !x_noclaim)
+          probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
         episode_stats(bs, a, o.max_log2);
         begin_episode(b, a, seed, id);                                                 // :81
         key_s = state_key(b, salt, status);
         slot_s = probe_find(table, mask, key_s, q);
-      } else if (key_n == key_s) {  // invalid move: same state, its row just changed (:100)
+      } else if (same) {            // invalid move: same state, its row just changed (:100)
         if (updated) row_set(q, act, nq);
+        else slot_s = kNoSlot;      // dropped: do not retry the claim with a stale hint
       } else {
         key_s = key_n; slot_s = slot_n; q = qn;                                        // :100
+        if (!x_noclaim) claim_issue(table, slot_s, key_s, claim);
       }
+      n_valid += wave_count(o.valid != 0);
+      n_explore += wave_count(explored);
+      n_insert += wave_count(ins_s) + wave_count(ins_n);
+      n_drop += wave_count(!updated);
+      n_done += wave_count(o.done != 0);
+      reward_sum += (double)o.reward;
     }
+    bool ins_last = false;  // the claim issued by the last step (its row belongs to the dict too)
+    claim_resolve(table, mask, key_s, claim, slot_s, ins_last);
+    n_insert += wave_count(ins_last);
     st_board(boards, i, b);
     st_aux(aux, i, a);
 

@@ -44,15 +44,28 @@ def parse_args():
     p.add_argument("--steps", type=int, default=256)
     p.add_argument("--warmup", type=int, default=64)
     p.add_argument("--boards-per-gpu", type=int, default=1 << 20)
-    p.add_argument("--steps-per-launch", type=int, default=16,
+    p.add_argument("--steps-per-launch", type=int, default=64,
                    help="env steps per fused launch (boards stay in registers in between)")
     p.add_argument("--eps", type=float, default=0.95)
     p.add_argument("--alpha", type=float, default=0.1)
     p.add_argument("--gamma", type=float, default=0.99)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--cap-log2", type=int, default=0, help="0 = sized from steps (load <= 0.5)")
+    p.add_argument("--strict-td", action="store_true",
+                   help="TD write by compare-and-swap loop (Q2048_FLAG_TD_CAS) instead of one store")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 = skip")
     return p.parse_args()
+
+
+def pmc_traffic_per_env_step():
+    """HBM-side bytes per env-step from the committed rocprofv3 PMC passes (profiles/), or None.
+    Collected in separate --pmc passes on the same bench command (tools/pmc_session.sh)."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
 
 
 def table_capacity_log2(boards: int, total_steps: int) -> int:
@@ -68,12 +81,12 @@ def cpu_baseline(args, seconds: float) -> dict:
     O.lib()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     best = None
-    for T in sorted({1, max(1, cores // 2), cores}):
+    for T in sorted({1, max(1, cores // 4), cores}):
         B, steps = 16384 * T, 24
         envs = O.envs_init(B, 4, args.seed, 0)
         agents = [O.Agent(1000, 4, args.alpha, args.gamma, args.eps) for _ in range(T)]
         for a in agents:
-            a.reserve(2 * B * 64 // T)
+            a.reserve(16384 * 64)      # rows one thread can create in this sample (no rehash)
         O.rollout_mt(envs, agents, 8, args.seed, 0, 0)                 # warm-up
         done, t0 = 0, time.perf_counter()
         budget = seconds / 3
@@ -117,7 +130,8 @@ def main():
     env = pkg.BatchedGame2048Env(shard.num_envs, seed=args.seed, env_id0=shard.env_id0, device=dev)
     agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
                                       exploration_rate=args.eps, capacity_log2=cap_log2,
-                                      seed=args.seed, env_id0=shard.env_id0, device=dev)
+                                      seed=args.seed, env_id0=shard.env_id0, device=dev,
+                                      strict_td=args.strict_td)
 
     def run(steps):
         launches = 0
@@ -161,12 +175,17 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_fused_rollout", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-                "traffic": None,
+                "traffic": None,  # filled below from the committed PMC passes
                 "algorithmic_bytes_per_env_step": ALGO_BYTES_FUSED_4X4,
                 "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                 "note": f"register-resident, K={S} env steps per launch: boards/aux cross HBM once "
                         f"per launch, the figure counts them once per step (SURVEY 8(d))"}
 
+    pmc = pmc_traffic_per_env_step()
+    if pmc is not None:
+        roofline["traffic"] = pmc["bytes_per_env_step"] * shard.num_envs * (args.steps / launches)
+        roofline["traffic_source"] = pmc["source"]
+        roofline["traffic_bytes_per_env_step"] = pmc["bytes_per_env_step"]
     out = {
         "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_max * 1e3 / args.steps,
@@ -179,6 +198,7 @@ def main():
                    "steps_per_launch": S, "table_capacity_log2": cap_log2,
                    "table_bytes_per_gpu": (1 << cap_log2) * 32, "epsilon": args.eps,
                    "alpha": args.alpha, "gamma": args.gamma, "seed": args.seed,
+                   "td_write": "compare-and-swap" if args.strict_td else "store (last writer wins)",
                    "parallelism": f"env-batch x{world}, RCCL all-reduce of statistics only"},
         "roofline": roofline,
         "stats": {"episodes": st["episodes"], "mean_return": st["mean_return"],

@@ -57,6 +57,10 @@ extern "C" {
 
 /* flags */
 #define Q2048_FLAG_INDEPENDENT 1u /* every env owns private Q rows (key salted by its global id) */
+#define Q2048_FLAG_SINGLE_ENV 2u  /* q_lookup: every board belongs to env `env_id0` (not env_id0 + i) */
+#define Q2048_FLAG_TD_CAS 4u      /* TD update by a compare-and-swap loop: concurrent updates of one
+                                     (s, a) serialise instead of "last writer wins"; identical to
+                                     the default whenever no two lanes share (s, a) */
 
 /* per-env state, Game2048_env.__init__ (Game2048_env.py:81-95) + episode bookkeeping */
 typedef struct q2048_aux {
@@ -140,9 +144,11 @@ int q2048_q_choose_draws(const q2048_slot *table, int cap_log2, const uint8_t *b
                          uint32_t *status, void *stream);
 
 /* QLearningAgent.update_q_value(state, action, reward, next_state, done)
- * (Agent/main.py:40-43) for B transitions.  Each lane applies the reference update to the
- * CURRENT value of Q[s][a] with a compare-and-swap loop, so concurrent updates of one entry
- * serialise (none is lost or summed); rows are created on first update. */
+ * (Agent/main.py:40-43) for B transitions.  Rows for next_state and state are created when
+ * absent, as the reference's defaultdict does (:41-43).  Q[s][a] is written with one 4-byte
+ * store: lanes that update the same (s, a) concurrently race and the last writer wins
+ * (Q2048_FLAG_TD_CAS serialises them with a compare-and-swap loop instead).  With one lane, or
+ * lanes on disjoint states, this is exactly the reference's sequential update. */
 int q2048_q_update(q2048_slot *table, int cap_log2, const uint8_t *boards_s,
                    const uint8_t *actions, const float *reward, const uint8_t *boards_s2,
                    const uint8_t *done, int64_t B, int n, double lr, double gamma,
