@@ -229,10 +229,35 @@ Q_HD double lut_pow12(uint32_t L) { constexpr double t[32] = Q2048_POW12; return
 Q_HD double lut_log2p1(uint32_t L) { constexpr double t[32] = Q2048_LOG2P1; return t[L & 31u]; }
 Q_HD double lut_stall(uint32_t k) { constexpr double t[32] = Q2048_STALL; return t[k < 31u ? k : 31u]; }
 
-// update_and_normalize (:197-205)
+Q_HD uint64_t f64_bits(double d) { union { double d; uint64_t u; } c; c.d = d; return c.u; }
+Q_HD double bits_f64(uint64_t u) { union { double d; uint64_t u; } c; c.u = u; return c.d; }
+
+// log2(x) for finite x >= 1, relative error < 2^-46 (checked against libm in
+// tests/test_core_host.py): ~20 instructions instead of the math library's ~110.  The reward is
+// stored as float32, so this is >20 bits more than the rounding it feeds.
+//   x = m * 2^e, m in [1, 2);  j = top 6 mantissa bits;  r = m * inv[j] - 1, |r| <= 2^-7;
+//   log2(x) = e + lg[j] + r * (a1 + r * (a2 + ... + r * a6)),  lg[j] = -log2(inv[j]) exactly.
+Q_HD double log2_ge1(double x) {
+  constexpr double inv[64] = Q2048_LOG2_INV;
+  constexpr double lg[64] = Q2048_LOG2_LG;
+  constexpr double a[6] = Q2048_LOG2_COEF;
+  const uint64_t u = f64_bits(x);
+  const int e = (int)(u >> 52) - 1023;
+  const uint32_t j = (uint32_t)(u >> 46) & 63u;
+  const double m = bits_f64((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+  const double r = fma(m, inv[j], -1.0);
+  double p = fma(r, a[5], a[4]);
+  p = fma(r, p, a[3]);
+  p = fma(r, p, a[2]);
+  p = fma(r, p, a[1]);
+  p = fma(r, p, a[0]);
+  return fma(r, p, (double)e + lg[j]);
+}
+
+// update_and_normalize (:197-205); both log2 arguments are >= 1
 Q_HD double normalize_reward(double r) {
-  if (r >= 0) return fmin(log2(r + 1), 10.0);
-  return -fmin(log2(fabs(r - 1)), 10.0);
+  if (r >= 0) return fmin(log2_ge1(r + 1), 10.0);
+  return -fmin(log2_ge1(fabs(r - 1)), 10.0);
 }
 
 // calculate_reward (:136-184); L = log2(max tile), prev = log2(previous_max), both integers

@@ -141,6 +141,10 @@ void hc_luts(double* pow12, double* log2p1, double* stall) {
   }
 }
 
+void hc_log2_ge1(const double* x, int64_t n, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = log2_ge1(x[i]);
+}
+
 uint64_t hc_mix64(uint64_t x) { return mix64(x); }
 uint64_t hc_lane_salt(uint64_t id) { return lane_salt(id); }
 int hc_sizeof_aux(void) { return (int)sizeof(Aux); }

@@ -5,7 +5,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG/pmc
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 64 --warmup 64 --steps-per-launch 16 --cpu-seconds 0"
+BENCH="python3 bench.py --cpu-seconds 0"
 rocprofv3 -L > "$OUT/counters_list.txt" 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_EA0_ATOMIC_sum" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
@@ -17,4 +17,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCC_EA0_ATOMIC_sum" "TCC_HIT_sum TCC_MISS_su
   rc=$?; echo "rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
 done
-python3 tools/pmc_summary.py "$OUT" | tee "$OUT/summary.txt"
+python3 tools/pmc_summary.py "$OUT" 1048576 64 | tee "$OUT/summary.txt"

@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""train.py -- the episode loop of the reference (QLearningBase/Agent/main.py:65-115) on MI355X.
+
+The reference's README advertises `python train.py --episodes N --alpha A --gamma G --epsilon E`
+(README.md:62-75) but ships no such file: its training loop is the `__main__` block of
+Agent/main.py with every hyper-parameter a literal (:67-68).  This script is that loop with the
+README flags, in two modes:
+
+  --num-envs 1   the reference loop body, line for line, on the drop-in adapters
+                 (Game2048_env / QLearningAgent with the reference's Python types), one CSV row
+                 per finished episode with the reference's header (Agent/main.py:71-76).
+  --num-envs B   B boards per GPU through the fused rollout kernel (`--steps-per-launch` env
+                 steps per launch); epsilon decays once per `B` finished episodes (one "epoch" =
+                 one episode per env on average); one CSV row per report interval with the
+                 aggregated statistics.  Under torchrun every rank trains its own shard of the
+                 env batch and its own Q-table replica; only the statistics are all-reduced.
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--episodes", type=int, default=1000, help="total episodes (per env on average)")
+    p.add_argument("--alpha", type=float, default=0.1, help="learning rate (README.md:66)")
+    p.add_argument("--gamma", type=float, default=0.99, help="discount factor (README.md:67)")
+    p.add_argument("--epsilon", type=float, default=0.95, help="initial exploration rate (README.md:68)")
+    p.add_argument("--epsilon-min", type=float, default=0.01)
+    p.add_argument("--num-envs", type=int, default=1, help="boards per GPU")
+    p.add_argument("--board-size", type=int, default=4)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--device", default="cuda")
+    p.add_argument("--steps-per-launch", type=int, default=64)
+    p.add_argument("--capacity-log2", type=int, default=0, help="Q-table slots = 2^n (0 = auto)")
+    p.add_argument("--strict-td", action="store_true", help="compare-and-swap TD writes")
+    p.add_argument("--log", default="debug_log.csv", help="CSV log path (Agent/main.py:71)")
+    p.add_argument("--report-every", type=int, default=10, help="launches between CSV rows (batched)")
+    p.add_argument("--max-steps", type=int, default=0, help="stop after this many env steps per env (0 = off)")
+    return p.parse_args(argv)
+
+
+def log_debug_info(file_path, episode, action, q_values, reward, total_reward, max_value):
+    """Agent/main.py:59-62."""
+    with open(file_path, mode="a", newline="") as file:
+        csv.writer(file).writerow([episode, action, q_values, reward, total_reward, max_value])
+
+
+def train_single(args, pkg):
+    """Agent/main.py:65-115 with the adapters: the loop body below is the reference's."""
+    env = pkg.Game2048_env(device=args.device, seed=args.seed)                         # :66
+    num_episodes = args.episodes                                                       # :67
+    agent = pkg.QLearningAgent(num_episodes, action_space=env.action_space.n,          # :68
+                               learning_rate=args.alpha, discount_factor=args.gamma,
+                               exploration_rate=args.epsilon, exploration_min=args.epsilon_min,
+                               capacity_log2=args.capacity_log2 or 22, device=args.device,
+                               seed=args.seed)
+    log_file = args.log                                                                # :71
+    with open(log_file, mode="w", newline="") as file:                                 # :74-76
+        csv.writer(file).writerow(["Episode", "Action", "Q-Values", "Reward", "Total-Reward", "Max Value"])
+    max_number_in_train = 0
+    t0, steps = time.time(), 0
+    for episode in range(num_episodes):                                                # :80
+        state = env.reset()                                                            # :81
+        state = tuple(map(tuple, state))                                               # :82
+        done = False
+        total_reward = 0
+        max_number_in_train = max(max_number_in_train, int(np.max(env.game.board)))    # :85-86
+        while not done:                                                                # :91
+            action = agent.choose_action(state)                                        # :92
+            next_state, reward, done, info = env.step(action)                          # :93
+            next_state = tuple(map(tuple, next_state))                                 # :94
+            agent.update_q_value(state, action, reward, next_state, done)              # :99
+            q_values = agent.q_table[state]                                            # :96 (post-update alias)
+            max_value = np.max(next_state)                                             # :97
+            state = next_state                                                         # :100
+            total_reward += reward                                                     # :101
+            steps += 1
+            if done:                                                                   # :103-105
+                log_debug_info(log_file, episode, action, q_values, reward, total_reward, max_value)
+        agent.decay_exploration(episode)                                               # :109
+        if episode % 100 == 0:
+            print(f"Episode {episode}: Total Reward: {total_reward} epsilon {agent.epsilon:.4f} "
+                  f"rows {len(agent.q_table)} steps/s {steps / (time.time() - t0):.0f}")
+    return agent
+
+
+def train_batched(args, pkg):
+    import torch
+
+    rank, local_rank, world = pkg.dist.init_process_group()
+    dev = torch.device(args.device if ":" in args.device or world == 1 else f"cuda:{local_rank}")
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", local_rank)
+    shard = pkg.weak_shard(args.num_envs, world, rank)
+    B = shard.num_envs
+    # ~220 steps per episode, most of them reach a new state: size for the whole run (load <= 0.5),
+    # capped at 2^32 slots = 128 GiB
+    cap = args.capacity_log2 or int(min(32, max(20, np.ceil(np.log2(2.0 * B * 256 * max(args.episodes, 1))))))
+    env = pkg.BatchedGame2048Env(B, args.board_size, dev, args.seed, shard.env_id0)
+    agent = pkg.BatchedQLearningAgent(args.episodes, 4, args.alpha, args.gamma, args.epsilon,
+                                      args.epsilon_min, cap, dev, args.seed, shard.env_id0,
+                                      strict_td=args.strict_td)
+    if rank == 0:
+        with open(args.log, mode="w", newline="") as fh:
+            csv.writer(fh).writerow(["Epoch", "Episodes", "Env-Steps", "Epsilon", "Mean-Return",
+                                     "Mean-Score", "Max Value", "Table-Rows", "Drops", "Steps/s"])
+    total_eps, epoch, launches, t0 = 0, 0, 0, time.time()
+    target = args.episodes * shard.total_envs
+    best_tile = 0
+    while total_eps < target:
+        agent.fused_rollout(env, args.steps_per_launch)
+        launches += 1
+        if launches % args.report_every and not args.max_steps:
+            continue
+        si, sf = agent.stats_i.clone(), agent.stats_f.clone()
+        pkg.allreduce_stats(si, sf)                       # the only collective: a few hundred bytes
+        st = pkg.stats_dict(si.cpu().numpy(), sf.cpu().numpy())
+        total_eps = st["episodes"]
+        while epoch < total_eps // shard.total_envs and epoch < args.episodes:
+            agent.decay_exploration(epoch)                # Agent/main.py:109, once per epoch
+            epoch += 1
+        best_tile = max(st["max_tile_hist"], default=0)
+        if rank == 0:
+            rate = st["steps"] / (time.time() - t0)
+            with open(args.log, mode="a", newline="") as fh:
+                csv.writer(fh).writerow([epoch, total_eps, st["steps"], f"{agent.epsilon:.6f}",
+                                         f"{st['mean_return']:.4f}", f"{st['mean_score']:.1f}", best_tile,
+                                         st["inserts"], st["drops"], f"{rate:.4e}"])
+            print(f"epoch {epoch}/{args.episodes} episodes {total_eps} steps {st['steps']} eps "
+                  f"{agent.epsilon:.4f} mean return {st['mean_return']:.3f} best tile {best_tile} "
+                  f"rows {st['inserts']} drops {st['drops']} {rate:.3e} env-steps/s", flush=True)
+        if args.max_steps and env.ctr >= args.max_steps:
+            break
+    agent.check_status()
+    return agent
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    pkg = importlib.import_module("2048_q-learning_amd")
+    if args.num_envs == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return train_single(args, pkg)
+    return train_batched(args, pkg)
+
+
+if __name__ == "__main__":
+    main()
