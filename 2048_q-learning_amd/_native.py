@@ -15,7 +15,7 @@ CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_PKG, "..", "include"))
 LIB_PATH = os.environ.get("Q2048_LIB_PATH") or os.path.join(CSRC, "libq2048_hip.so")  # override: experiments
 SOURCES = ["q2048_kernels.hip"]
-DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_luts.inc"]
+DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc"]
 
 OK = 0
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
@@ -86,14 +86,14 @@ _SIGNATURES = {
                                  C.c_double, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
     "q2048_q_lookup": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_uint64,
-                                 C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                 C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "q2048_fused_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
                                       C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double,
                                       C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "q2048_table_count": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "q2048_table_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
-                                     C.c_void_p, C.c_void_p]),
+                                     C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -76,10 +76,13 @@ class BatchedQLearningAgent:
     def __init__(self, total_epochs, action_space=4, learning_rate=0.1, discount_factor=0.9,
                  exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 24,
                  device="cuda", seed: int = 0, env_id0: int = 0, independent: bool = False,
-                 strict_td: bool = False):
+                 strict_td: bool = False, board_size: int = 4):
         self.device = _require_gpu(device)
         if action_space != 4:
             raise ValueError("the 2048 action space has 4 actions")
+        if board_size not in (4, 5):
+            raise NotImplementedError("board_size must be 4 (the reference) or 5")
+        self.board_size, self.cells = int(board_size), int(board_size) ** 2
         if not 4 <= capacity_log2 <= 40:
             raise ValueError("capacity_log2 must be in [4, 40]")
         self.action_space = action_space                                       # :21
@@ -121,7 +124,7 @@ class BatchedQLearningAgent:
         B = boards.shape[0]
         actions = torch.empty(B, dtype=torch.uint8, device=self.device)
         N.check(N.lib().q2048_q_choose(
-            _ptr(self.table), self.capacity_log2, _ptr(boards), B, 4, float(self.epsilon),
+            _ptr(self.table), self.capacity_log2, _ptr(boards), B, self.board_size, float(self.epsilon),
             self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self.flags, _ptr(actions),
             _ptr(self.status), _stream(self.device)), "q_choose")
         self.ctr += 1
@@ -136,7 +139,7 @@ class BatchedQLearningAgent:
         done = self._vec(done, torch.uint8, B, "done")
         N.check(N.lib().q2048_q_update(
             _ptr(self.table), self.capacity_log2, _ptr(boards), _ptr(actions), _ptr(reward),
-            _ptr(next_boards), _ptr(done), B, 4, float(self.lr), float(self.gamma), self.env_id0,
+            _ptr(next_boards), _ptr(done), B, self.board_size, float(self.lr), float(self.gamma), self.env_id0,
             self.flags, _ptr(self.stats_i), _ptr(self.status), _stream(self.device)), "q_update")
 
     def q_values(self, boards: torch.Tensor, env_id: int | None = None,
@@ -150,9 +153,9 @@ class BatchedQLearningAgent:
         found = torch.empty(B, dtype=torch.uint8, device=self.device) if return_found else None
         flags = self.flags | (N.FLAG_SINGLE_ENV if env_id is not None else 0)
         N.check(N.lib().q2048_q_lookup(
-            _ptr(self.table), self.capacity_log2, _ptr(boards), B, 4,
+            _ptr(self.table), self.capacity_log2, _ptr(boards), B, self.board_size,
             self.env_id0 if env_id is None else int(env_id), flags, _ptr(q), _ptr(found),
-            _stream(self.device)), "q_lookup")
+            _ptr(self.status), _stream(self.device)), "q_lookup")
         return (q, found.bool()) if return_found else q
 
     # -- throughput entry point ----------------------------------------------------------
@@ -164,11 +167,13 @@ class BatchedQLearningAgent:
             raise ValueError("env and agent live on different devices")
         if (env.seed, env.env_id0) != (self.seed, self.env_id0):
             raise ValueError("env and agent must share seed and env_id0 (one draw stream per env)")
+        if env.board_size != self.board_size:
+            raise ValueError("env and agent have different board sizes")
         if env.ctr != self.ctr:
             raise ValueError(f"env.ctr={env.ctr} and agent.ctr={self.ctr} are out of step")
         N.check(N.lib().q2048_fused_rollout(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
-            4, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
+            self.board_size, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
             self.env_id0, self.ctr & 0xFFFFFFFF, self.flags | self.experiment_bits,
             _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status), _stream(self.device)),
             "fused_rollout")
@@ -193,16 +198,19 @@ class BatchedQLearningAgent:
         return int(count.item())
 
     def export_rows(self):
-        """All occupied rows: (keys uint64 [R], q float32 [R,4]) on the host."""
+        """All occupied rows on the host: (keys uint64 [R] for 4x4 / [R, 2] for 5x5,
+        q float32 [R, 4])."""
         rows = self.table_size()
-        keys = torch.empty(max(rows, 1), dtype=torch.int64, device=self.device)
+        words = 1 if self.board_size == 4 else 2
+        keys = torch.empty((max(rows, 1), words), dtype=torch.int64, device=self.device)
         q = torch.empty((max(rows, 1), 4), dtype=torch.float32, device=self.device)
         count = torch.zeros(1, dtype=torch.int64, device=self.device)
         N.check(N.lib().q2048_table_export(_ptr(self.table), self.capacity_log2, _ptr(keys),
-                                           _ptr(q), rows, _ptr(count), _stream(self.device)),
+                                           _ptr(q), rows, words, _ptr(count), _stream(self.device)),
                 "table_export")
         got = min(int(count.item()), rows)
-        return keys[:got].cpu().numpy().view(np.uint64), q[:got].cpu().numpy()
+        k = keys[:got].cpu().numpy().view(np.uint64)
+        return (k[:, 0] if words == 1 else k), q[:got].cpu().numpy()
 
     def export_dict(self) -> dict:
         """The table in the reference's form: {tuple of 4 tuples of raw tile values ->
@@ -210,11 +218,15 @@ class BatchedQLearningAgent:
         if self.flags & N.FLAG_INDEPENDENT:
             raise ValueError("salted keys of independent mode do not decode to boards")
         keys, q = self.export_rows()
-        out = {}
+        out, n = {}, self.board_size
         for k, row in zip(keys.tolist(), q.astype(np.float64)):
-            cells = [(k >> (4 * c)) & 15 for c in range(16)]
+            if n == 4:
+                cells = [(k >> (4 * c)) & 15 for c in range(16)]
+            else:  # 125 bits: key bits 0..62, then reserved bits 0..61
+                big = (k[0] & ((1 << 63) - 1)) | ((k[1] & ((1 << 62) - 1)) << 63)
+                cells = [(big >> (5 * c)) & 31 for c in range(25)]
             raw = [0 if v == 0 else 1 << v for v in cells]
-            out[tuple(tuple(raw[4 * r:4 * r + 4]) for r in range(4))] = row
+            out[tuple(tuple(raw[n * r:n * r + n]) for r in range(n))] = row
         return out
 
     def check_status(self) -> int:
@@ -231,8 +243,8 @@ class BatchedQLearningAgent:
         if b.dtype != torch.uint8:
             raise TypeError("boards must be uint8 log2 tiles")
         b = b.to(self.device)
-        if b.dim() != 2 or b.shape[1] != 16:
-            raise ValueError(f"boards must have shape (B, 16), got {tuple(b.shape)}")
+        if b.dim() != 2 or b.shape[1] != self.cells:
+            raise ValueError(f"boards must have shape (B, {self.cells}), got {tuple(b.shape)}")
         return b.contiguous()
 
     def _vec(self, v, dtype, B, name) -> torch.Tensor:

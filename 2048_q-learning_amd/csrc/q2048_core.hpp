@@ -82,6 +82,7 @@ struct Board { uint32_t r0, r1, r2, r3; };
 Q_HD bool operator==(const Board& a, const Board& b) {
   return ((a.r0 ^ b.r0) | (a.r1 ^ b.r1) | (a.r2 ^ b.r2) | (a.r3 ^ b.r3)) == 0;
 }
+Q_HD void clear(Board& b) { b = Board{0u, 0u, 0u, 0u}; }
 
 // 4x4 byte transpose: out word j = column j (byte i = row i)
 Q_HD Board transpose(const Board& b) {
@@ -292,8 +293,10 @@ struct StepOut {
   uint8_t done, max_log2, valid;
 };
 
-// Game2048_env.step (:97-129) for one lane.  x_pos/x_val are the spawn draws.
-Q_HD StepOut env_step(Board& b, Aux& a, int action, uint32_t x_pos, uint32_t x_val) {
+// Game2048_env.step (:97-129) for one lane.  x_pos/x_val are the spawn draws.  BoardT is the
+// 4x4 Board above or the 5x5 Board5 of q2048_core5.hpp (same functions, overloaded).
+template <class BoardT>
+Q_HD StepOut env_step(BoardT& b, Aux& a, int action, uint32_t x_pos, uint32_t x_val) {
   StepOut o;
   uint32_t score;
   const bool valid = move(b, action, score);                            // :98
@@ -327,8 +330,9 @@ Q_HD StepOut env_step(Board& b, Aux& a, int action, uint32_t x_pos, uint32_t x_v
 
 // Game2048.__init__ (:11-14) / Game2048_env.reset (:187-191): empty board, two spawns,
 // score = 0.  previous_max and the consecutive-action state are NOT reset (:187-191).
-Q_HD void reset_board(Board& b, Aux& a, const Draws& d) {
-  b = Board{0u, 0u, 0u, 0u};
+template <class BoardT>
+Q_HD void reset_board(BoardT& b, Aux& a, const Draws& d) {
+  clear(b);
   spawn(b, d.x0, d.x1);
   spawn(b, d.x2, d.x3);
   a.score = 0;
@@ -337,11 +341,13 @@ Q_HD void reset_board(Board& b, Aux& a, const Draws& d) {
 
 // env construction (Game2048_env.__init__, :81-95) and the reset that follows a finished
 // episode (Agent/main.py:81): the spawn draws are keyed by (env id, episode index)
-Q_HD void init_env(Board& b, Aux& a, uint64_t seed, uint64_t env_id) {
+template <class BoardT>
+Q_HD void init_env(BoardT& b, Aux& a, uint64_t seed, uint64_t env_id) {
   a = aux_init();
   reset_board(b, a, draws(seed, env_id, 0u, kStreamReset));
 }
-Q_HD void begin_episode(Board& b, Aux& a, uint64_t seed, uint64_t env_id) {
+template <class BoardT>
+Q_HD void begin_episode(BoardT& b, Aux& a, uint64_t seed, uint64_t env_id) {
   a.episode += 1u;
   reset_board(b, a, draws(seed, env_id, a.episode, kStreamReset));
 }

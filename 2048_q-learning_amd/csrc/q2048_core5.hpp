@@ -1,0 +1,214 @@
+// q2048_core5.hpp -- per-lane arithmetic of the 5x5 board variant (BASELINE configs[4]).
+//
+// The reference hard-codes a 4x4 board (environment/Game2048_env.py:12,41); 5x5 is the same
+// algorithm with n = 5 (the oracle restates every function for general n and is pinned to the
+// reference at n = 4).  A board is five 32-bit row words, cell c of a row in the 6-bit field at
+// bit 6c: 5 value bits (log2 tile <= 31) + 1 guard bit for the SWAR compares.  The functions
+// mirror q2048_core.hpp one for one (same names, overloaded on the board type), so the env step
+// and the kernels are written once over both geometries.
+#pragma once
+#include "q2048_core.hpp"
+
+namespace q2048 {
+
+struct Board5 { uint32_t r[5]; };
+
+constexpr uint32_t k5One = 0x01041041u;   // bit 0 of each of the five 6-bit fields
+constexpr uint32_t k5Low = k5One * 31u;   // 0x1f per field
+constexpr uint32_t k5High = k5One << 5;   // guard bit per field
+constexpr uint32_t k5All = k5One * 63u;
+
+Q_HD uint32_t nz5(uint32_t x) { return (x + k5Low) & k5High; }    // guard bit set per field != 0
+Q_HD uint32_t z5(uint32_t x) { return ~(x + k5Low) & k5High; }    // guard bit set per field == 0
+Q_HD uint32_t fill5(uint32_t m) { return (m << 1) - (m >> 5); }   // guard bit -> 0x3f field
+Q_HD uint32_t field5(uint32_t w, int c) { return (w >> (6 * c)) & 63u; }
+
+Q_HD bool operator==(const Board5& a, const Board5& b) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) d |= a.r[i] ^ b.r[i];
+  return d == 0;
+}
+Q_HD void clear(Board5& b) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i) b.r[i] = 0u;
+}
+
+// out word j = column j (field i = row i)
+Q_HD Board5 transpose(const Board5& b) {
+  Board5 t;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) w |= field5(b.r[i], j) << (6 * i);
+    t.r[j] = w;
+  }
+  return t;
+}
+
+Q_HD uint32_t pow2_sum5(uint32_t v) {  // sum over the five fields f of (f ? 2^f : 0), f >= 2
+  uint32_t s = 0;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) s += (1u << field5(v, c)) & ~1u;
+  return s;
+}
+
+// move_left (Game2048_env.py:25-44) on five lines at once; c[j] = cell j of every line
+Q_HD uint32_t slide_lines(uint32_t (&c)[5]) {
+  // compress (:26)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int rep = 0; rep < 4 - t; ++rep) {
+      const uint32_t z = fill5(z5(c[t]));
+#pragma unroll
+      for (int k = t; k < 4; ++k) c[k] = bsel(z, c[k + 1], c[k]);
+      c[4] &= ~z;
+    }
+  }
+  // merge (:29-40): pairs left to right, a merged tile never merges again
+  uint32_t score = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint32_t e = z5(c[t] ^ c[t + 1]) & nz5(c[t]);
+    const uint32_t m = fill5(e);
+    c[t] += e >> 5;
+    score += pow2_sum5(c[t] & m);  // :36
+#pragma unroll
+    for (int k = t + 1; k < 4; ++k) c[k] = bsel(m, c[k + 1], c[k]);
+    c[4] &= ~m;
+  }
+  return score;
+}
+
+// Game2048.move without the spawn (:51-60); 0 left, 1 up, 2 right, 3 down (:54)
+Q_HD bool move(Board5& b, int action, uint32_t& score) {
+  const bool horiz = (action & 1) == 0, rev = (action & 2) != 0;
+  const Board5 t = transpose(b);
+  uint32_t p[5], c[5], o[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) p[j] = horiz ? t.r[j] : b.r[j];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) { c[j] = rev ? p[4 - j] : p[j]; o[j] = c[j]; }
+  score = slide_lines(c);
+  uint32_t diff = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) diff |= c[j] ^ o[j];
+  Board5 q;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) q.r[j] = rev ? c[4 - j] : c[j];
+  const Board5 qt = transpose(q);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) b.r[j] = horiz ? qt.r[j] : q.r[j];
+  return diff != 0;  // :38,42-43
+}
+
+// guard bits (5,11,17,23,29) of a row -> 5 contiguous bits
+Q_HD uint32_t movemask5(uint32_t g) { return (((g >> 5) * 0x01084210u) >> 24) & 31u; }
+// 25-bit mask of empty cells, bit = row-major cell index (np.where order, :17)
+Q_HD uint32_t empty_mask(const Board5& b) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) m |= movemask5(z5(b.r[i])) << (5 * i);
+  return m;
+}
+
+// index of the k-th (0-based) set bit of a 32-bit mask, k < popcount(mask)
+Q_HD uint32_t kth_set_bit32(uint32_t mask, uint32_t k) {
+  uint32_t pos = 0, c;
+  bool ge;
+  c = popc(mask & 0xffffu); ge = k >= c; k -= ge ? c : 0u; pos += ge ? 16u : 0u; mask >>= ge ? 16u : 0u;
+  c = popc(mask & 0xffu);   ge = k >= c; k -= ge ? c : 0u; pos += ge ? 8u : 0u;  mask >>= ge ? 8u : 0u;
+  c = popc(mask & 0xfu);    ge = k >= c; k -= ge ? c : 0u; pos += ge ? 4u : 0u;  mask >>= ge ? 4u : 0u;
+  c = popc(mask & 0x3u);    ge = k >= c; k -= ge ? c : 0u; pos += ge ? 2u : 0u;  mask >>= ge ? 2u : 0u;
+  c = mask & 1u;            ge = k >= c; pos += ge ? 1u : 0u;
+  return pos;
+}
+
+Q_HD void put_cell(Board5& b, uint32_t pos, uint32_t v) {
+  const uint32_t row = (pos * 52429u) >> 18;  // pos / 5 for pos < 25
+  const uint32_t w = v << (6u * (pos - 5u * row));
+#pragma unroll
+  for (int i = 0; i < 5; ++i) b.r[i] |= row == (uint32_t)i ? w : 0u;
+}
+
+// Game2048.add_number (:16-20)
+Q_HD void spawn(Board5& b, uint32_t draw_pos, uint32_t draw_val) {
+  const uint32_t em = empty_mask(b), n = popc(em);
+  if (n == 0u) return;  // :18
+  put_cell(b, kth_set_bit32(em, draw_index(draw_pos, n)), draw_is_four(draw_val) ? 2u : 1u);
+}
+
+// Game2048.is_game_over (:65-75), closed form
+Q_HD bool game_over(const Board5& b) {
+  uint32_t live = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    live |= z5(b.r[i]);                                          // an empty cell
+    live |= z5(b.r[i] ^ (b.r[i] >> 6)) & (k5High >> 6);          // equal horizontal neighbours
+    if (i < 4) live |= z5(b.r[i] ^ b.r[i + 1]);                  // equal vertical neighbours
+  }
+  return live == 0u;
+}
+
+Q_HD uint32_t fieldmax5(uint32_t a, uint32_t b) {
+  const uint32_t m = fill5(((a | k5High) - b) & k5High);
+  return bsel(m, a, b);
+}
+Q_HD uint32_t max_log2(const Board5& b) {
+  uint32_t x = fieldmax5(fieldmax5(b.r[0], b.r[1]), fieldmax5(fieldmax5(b.r[2], b.r[3]), b.r[4]));
+  uint32_t m = field5(x, 0);
+#pragma unroll
+  for (int c = 1; c < 5; ++c) { const uint32_t f = field5(x, c); m = f > m ? f : m; }
+  return m;
+}
+
+// state key (Agent/main.py:82): 25 cells x 5 bits = 125 bits in two words, each with bit 63 set
+// so that neither is ever 0 (0 marks an empty / not yet published key word)
+struct Key5 { uint64_t k0, k1; };
+Q_HD uint32_t pack_row5(uint32_t r) {  // five 6-bit fields -> 25 contiguous bits
+  return (r & 31u) | ((r >> 1) & (31u << 5)) | ((r >> 2) & (31u << 10)) | ((r >> 3) & (31u << 15)) |
+         ((r >> 4) & (31u << 20));
+}
+Q_HD Key5 pack_key(const Board5& b) {
+  const uint64_t p0 = pack_row5(b.r[0]), p1 = pack_row5(b.r[1]), p2 = pack_row5(b.r[2]),
+                 p3 = pack_row5(b.r[3]), p4 = pack_row5(b.r[4]);
+  return Key5{(p0 | (p1 << 25) | ((p2 & 0x1fffull) << 50)) | (1ull << 63),
+              ((p2 >> 13) | (p3 << 12) | (p4 << 37)) | (1ull << 63)};
+}
+Q_HD uint32_t unpack_row5(uint32_t p) {
+  return (p & 31u) | ((p & (31u << 5)) << 1) | ((p & (31u << 10)) << 2) | ((p & (31u << 15)) << 3) |
+         ((p & (31u << 20)) << 4);
+}
+Q_HD Board5 unpack_key(const Key5& k) {
+  const uint64_t a = k.k0 & ~(1ull << 63), c = k.k1 & ~(1ull << 63);
+  Board5 b;
+  b.r[0] = unpack_row5((uint32_t)(a & 0x1ffffffull));
+  b.r[1] = unpack_row5((uint32_t)((a >> 25) & 0x1ffffffull));
+  b.r[2] = unpack_row5((uint32_t)(((a >> 50) & 0x1fffull) | ((c & 0xfffull) << 13)));
+  b.r[3] = unpack_row5((uint32_t)((c >> 12) & 0x1ffffffull));
+  b.r[4] = unpack_row5((uint32_t)((c >> 37) & 0x1ffffffull));
+  return b;
+}
+
+// memory image: uint8[25] row-major log2 tiles <-> fields
+Q_HD Board5 board5_from_bytes(const uint8_t* p) {
+  Board5 b;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) w |= ((uint32_t)p[5 * i + c] & 31u) << (6 * c);
+    b.r[i] = w;
+  }
+  return b;
+}
+Q_HD void board5_to_bytes(const Board5& b, uint8_t* p) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) p[5 * i + c] = (uint8_t)(field5(b.r[i], c) & 31u);
+}
+
+}  // namespace q2048

@@ -1,18 +1,21 @@
 // q2048_kernels.hip -- gfx950 kernels + the C ABI of include/q2048.h.
 //
 // Layout in HBM (all caller-owned):
-//   boards  uint8[B][16]   one dwordx4 per lane, perfectly coalesced (1 KiB per wave access)
+//   boards  uint8[B][n*n]  4x4: one dwordx4 per lane, perfectly coalesced (1 KiB per wave access)
+//                          5x5: 25 B per board, unpadded; a block moves its 6400 contiguous
+//                          bytes with 16-byte accesses through LDS and each lane picks its 25
 //   aux     16 B per env   one dwordx4 per lane
-//   table   32 B slots     {u64 key, f32 q[4], u64 reserved}; random access, one 64-B line
-//                          per probe; linear probing keeps collisions in the same line
+//   table   32 B slots     {u64 key, f32 q[4], u64 key_hi}; random access, one 64-B line per
+//                          probe; linear probing keeps collisions in the same line
 // One board per lane.  Boards, aux and the carried Q row live in VGPRs for a whole launch;
 // per-step boolean statistics are wave ballots accumulated in SGPRs, rare per-episode
 // statistics go through LDS, and each block ends with one global atomic per statistic.
+// Every kernel is written once over the board geometry (template <int N>, N = 4 or 5).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "q2048.h"
-#include "q2048_core.hpp"
+#include "q2048_core5.hpp"
 
 namespace {
 using namespace q2048;
@@ -27,15 +30,66 @@ static_assert(sizeof(Aux) == sizeof(q2048_aux), "core/ABI aux mismatch");
 using u64 = unsigned long long;
 
 // ---------------------------------------------------------------------------------------------
-// coalesced 16-byte images
+// geometry: board type, state key, HBM image
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ Board ld_board(const uint8_t* boards, int64_t i) {
+template <int N> struct Geo;
+template <> struct Geo<4> {
+  using BoardT = Board;
+  struct Key { u64 k0; };
+};
+template <> struct Geo<5> {
+  using BoardT = Board5;
+  struct Key { u64 k0, k1; };
+};
+
+// LDS staging of one block's 5x5 boards (256 x 25 B = 400 x 16 B); empty for 4x4
+template <int N> struct Stage { };
+template <> struct Stage<5> { uint4 v[(kBlock * 25 + 15) / 16]; };
+
+// All threads of the block call these (the 5x5 path synchronises); lanes with i >= B get an
+// all-zero board and store nothing.
+__device__ __forceinline__ Board load_board(const uint8_t* boards, int64_t i, int64_t B, Stage<4>&) {
+  if (i >= B) return Board{0u, 0u, 0u, 0u};
   const uint4 v = reinterpret_cast<const uint4*>(boards)[i];
   return Board{v.x, v.y, v.z, v.w};
 }
-__device__ __forceinline__ void st_board(uint8_t* boards, int64_t i, const Board& b) {
-  reinterpret_cast<uint4*>(boards)[i] = make_uint4(b.r0, b.r1, b.r2, b.r3);
+__device__ __forceinline__ void store_board(uint8_t* boards, int64_t i, int64_t B, const Board& b,
+                                            Stage<4>&) {
+  if (i < B) reinterpret_cast<uint4*>(boards)[i] = make_uint4(b.r0, b.r1, b.r2, b.r3);
 }
+__device__ __forceinline__ Board5 load_board(const uint8_t* boards, int64_t i, int64_t B, Stage<5>& st) {
+  const int64_t base = (int64_t)blockIdx.x * kBlock;
+  const int64_t left = B - base;
+  const int bytes = (int)(left < kBlock ? left : kBlock) * 25;
+  const uint8_t* src = boards + base * 25;  // base * 25 = blockIdx * 6400: 16-byte aligned
+  uint8_t* lds = reinterpret_cast<uint8_t*>(st.v);
+  for (int c = threadIdx.x; c * 16 < bytes; c += kBlock) {
+    if (c * 16 + 16 <= bytes) st.v[c] = reinterpret_cast<const uint4*>(src)[c];
+    else for (int k = c * 16; k < bytes; ++k) lds[k] = src[k];  // ragged tail of the last block
+  }
+  __syncthreads();
+  Board5 b;
+  if (i < B) b = board5_from_bytes(lds + threadIdx.x * 25);
+  else clear(b);
+  __syncthreads();
+  return b;
+}
+__device__ __forceinline__ void store_board(uint8_t* boards, int64_t i, int64_t B, const Board5& b,
+                                            Stage<5>& st) {
+  const int64_t base = (int64_t)blockIdx.x * kBlock;
+  const int64_t left = B - base;
+  const int bytes = (int)(left < kBlock ? left : kBlock) * 25;
+  uint8_t* dst = boards + base * 25;
+  uint8_t* lds = reinterpret_cast<uint8_t*>(st.v);
+  if (i < B) board5_to_bytes(b, lds + threadIdx.x * 25);
+  __syncthreads();
+  for (int c = threadIdx.x; c * 16 < bytes; c += kBlock) {
+    if (c * 16 + 16 <= bytes) reinterpret_cast<uint4*>(dst)[c] = st.v[c];
+    else for (int k = c * 16; k < bytes; ++k) dst[k] = lds[k];
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ Aux ld_aux(const q2048_aux* aux, int64_t i) {
   const uint4 v = reinterpret_cast<const uint4*>(aux)[i];
   return words_to_aux(Words4{v.x, v.y, v.z, v.w});
@@ -45,22 +99,42 @@ __device__ __forceinline__ void st_aux(q2048_aux* aux, int64_t i, const Aux& a) 
   reinterpret_cast<uint4*>(aux)[i] = make_uint4(w.w0, w.w1, w.w2, w.w3);
 }
 
+// state keys.  Independent mode salts the key with the env id (private rows per env).
+__device__ __forceinline__ Geo<4>::Key state_key(const Board& b, u64 salt, uint32_t* status) {
+  bool ov;
+  u64 k = pack_key(b, ov) ^ salt;
+  if (ov) atomicOr(status, Q2048_STATUS_TILE_OVERFLOW);
+  return Geo<4>::Key{k == 0ull ? 1ull : k};  // 0 marks an empty slot
+}
+__device__ __forceinline__ Geo<5>::Key state_key(const Board5& b, u64 salt, uint32_t*) {
+  const Key5 k = pack_key(b);  // both words carry bit 63, so neither is ever 0
+  return Geo<5>::Key{k.k0 ^ (salt & 0x7fffffffffffffffull),
+                     k.k1 ^ (mix64(salt) & 0x3fffffffffffffffull)};
+}
+__device__ __forceinline__ bool key_eq(const Geo<4>::Key& a, const Geo<4>::Key& b) { return a.k0 == b.k0; }
+__device__ __forceinline__ bool key_eq(const Geo<5>::Key& a, const Geo<5>::Key& b) {
+  return a.k0 == b.k0 && a.k1 == b.k1;
+}
+__device__ __forceinline__ u64 key_home(const Geo<4>::Key& k, u64 mask) { return mix64(k.k0) & mask; }
+__device__ __forceinline__ u64 key_home(const Geo<5>::Key& k, u64 mask) {
+  return mix64(k.k0 ^ (k.k1 * 0x9E3779B97F4A7C15ull)) & mask;
+}
+
 // ---------------------------------------------------------------------------------------------
 // hash table.  Readers use agent-scope relaxed loads (they bypass the per-CU L1, which other
-// CUs' atomics never refresh); writers use device-scope compare-and-swap.  Keys are written
-// once (0 -> key) and never change, so a stale read can only miss a brand-new row, which reads
-// as the zero row it still is for the reader.
+// CUs' atomics never refresh); rows are claimed with a device-scope compare-and-swap on the key
+// word.  Keys are written once (0 -> key) and never change, so a stale read can only miss a
+// brand-new row, which reads as the zero row it still is for the reader.  5x5 keys take two
+// words, claimed one after the other without ever waiting (see `confirm`).
 // ---------------------------------------------------------------------------------------------
 struct Row { float q0, q1, q2, q3; };
 
-__device__ __forceinline__ u64 ld_key(const q2048_slot* s) {
-  return __hip_atomic_load(const_cast<u64*>(reinterpret_cast<const u64*>(&s->key)),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ u64 ld_u64(const void* p) {
+  return __hip_atomic_load(const_cast<u64*>(reinterpret_cast<const u64*>(p)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ Row ld_row(const q2048_slot* s) {
-  u64* p = const_cast<u64*>(reinterpret_cast<const u64*>(&s->q[0]));
-  const u64 a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const u64 b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 a = ld_u64(&s->q[0]), b = ld_u64(&s->q[2]);
   return Row{bits_f32((uint32_t)a), bits_f32((uint32_t)(a >> 32)), bits_f32((uint32_t)b),
              bits_f32((uint32_t)(b >> 32))};
 }
@@ -72,17 +146,44 @@ __device__ __forceinline__ void row_set(Row& r, int a, float v) {
   r.q2 = a == 2 ? v : r.q2; r.q3 = a == 3 ? v : r.q3;
 }
 
-// Lookup without insertion.  Returns the slot index (>= 0) when the key is present; otherwise
-// ~h (< 0) where h is the empty slot that ended the probe -- the place an insert of this key
-// would claim -- or kNoSlot when the probe limit was hit.
+// `confirm`: the slot's first key word equals key.k0 (this lane just set it, or found it so).
+// Does the slot hold `key`?  4x4: yes.  5x5: the slot belongs to whoever sets the second word;
+// a lane that finds it still 0 completes the slot with its own second word by compare-and-swap
+// (`completed` = this lane created the row), so nobody ever waits for another lane's store --
+// wave-mates that lost the same claim included -- and the memory-side compare-and-swap also
+// settles a zero read from a stale L2 line.  The second word goes 0 -> value exactly once.
+__device__ __forceinline__ bool confirm(q2048_slot*, const Geo<4>::Key&, bool won, bool& completed) {
+  completed = won;
+  return true;
+}
+__device__ __forceinline__ bool confirm(q2048_slot* s, const Geo<5>::Key& key, bool, bool& completed) {
+  completed = false;
+  u64 hi = ld_u64(&s->reserved);
+  if (hi == 0ull) {
+    hi = atomicCAS(reinterpret_cast<u64*>(&s->reserved), 0ull, key.k1);
+    if (hi == 0ull) { completed = true; return true; }
+  }
+  return hi == key.k1;
+}
+
+// Lookup.  Returns the slot index (>= 0) when the key is present; otherwise ~h (< 0) where h is
+// the empty slot that ended the probe -- the place an insert of this key would claim -- or
+// kNoSlot when the probe limit was hit.  `created` is set when this lane completed a half-made
+// 5x5 row on the way (it then owns a fresh zero row); it never is on 4x4.
 constexpr int64_t kNoSlot = INT64_MIN;
-__device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask, u64 key, Row& row) {
-  u64 i = mix64(key) & mask;
+template <class Key>
+__device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask, const Key& key,
+                                              Row& row, bool& created) {
+  u64 i = key_home(key, mask);
   row = Row{0.f, 0.f, 0.f, 0.f};
+  created = false;
   for (int p = 0; p < kMaxProbe; ++p) {
-    const u64 k = ld_key(&table[i]);
-    if (k == key) { row = ld_row(&table[i]); return (int64_t)i; }
+    const u64 k = ld_u64(&table[i].key);
     if (k == 0ull) return ~(int64_t)i;
+    if (k == key.k0 && confirm(const_cast<q2048_slot*>(&table[i]), key, false, created)) {
+      if (!created) row = ld_row(&table[i]);
+      return (int64_t)i;
+    }
     i = (i + 1ull) & mask;
   }
   return kNoSlot;
@@ -91,22 +192,50 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
 // Find-or-create starting at slot `start` (the hint of a failed probe_find, or the home slot).
 // The first access is the claiming compare-and-swap itself: the slot was empty a moment ago.
 // Returns the slot index or kNoSlot (probe limit: the caller drops the update).
-__device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, u64 key, u64 start,
+template <class Key>
+__device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, const Key& key, u64 start,
                                                 bool& inserted) {
   u64 i = start & mask;
   inserted = false;
-  u64 k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key);
-  if (k == 0ull) { inserted = true; return (int64_t)i; }
+  u64 k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key.k0);
   for (int p = 0; p < kMaxProbe; ++p) {
-    if (k == key) return (int64_t)i;
+    if ((k == 0ull || k == key.k0) && confirm(&table[i], key, k == 0ull, inserted)) return (int64_t)i;
     i = (i + 1ull) & mask;
-    k = ld_key(&table[i]);
-    if (k == 0ull) {
-      k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key);
-      if (k == 0ull) { inserted = true; return (int64_t)i; }
-    }
+    k = ld_u64(&table[i].key);
+    if (k == 0ull) k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key.k0);
   }
+  inserted = false;
   return kNoSlot;
+}
+
+// A row claim in flight (4x4): the compare-and-swap was issued, its result is consumed one step
+// later, so the round trip hides behind the next step's arithmetic.  5x5 claims synchronously
+// (the second key word has to follow the first at once).
+struct Claim { u64 ret; u64 at; bool active; };
+
+__device__ __forceinline__ int64_t claim_issue(q2048_slot* table, u64, int64_t slot,
+                                               const Geo<4>::Key& key, Claim& c, bool&) {
+  c.active = slot < 0 && slot != kNoSlot;
+  if (c.active) {
+    c.at = (u64)~slot;
+    c.ret = atomicCAS(reinterpret_cast<u64*>(&table[c.at].key), 0ull, key.k0);
+  }
+  return slot;
+}
+__device__ __forceinline__ int64_t claim_issue(q2048_slot* table, u64 mask, int64_t slot,
+                                               const Geo<5>::Key& key, Claim& c, bool& inserted) {
+  c.active = false;
+  if (slot < 0 && slot != kNoSlot) return probe_insert(table, mask, key, (u64)~slot, inserted);
+  return slot;
+}
+template <class Key>
+__device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, const Key& key, Claim& c,
+                                                 int64_t slot, bool& inserted) {
+  if (!c.active) return slot;
+  c.active = false;
+  if (c.ret == 0ull) { inserted = true; return (int64_t)c.at; }
+  if (c.ret == key.k0) return (int64_t)c.at;
+  return probe_insert(table, mask, key, c.at + 1ull, inserted);  // another key took the slot
 }
 
 // update_q_value on one entry (Agent/main.py:43) against its CURRENT value.  `guess` is the
@@ -124,11 +253,11 @@ __device__ __forceinline__ float td_update(q2048_slot* slot, int a, float guess,
   unsigned int* addr = reinterpret_cast<unsigned int*>(&slot->q[a]);
   unsigned int expect = f32_bits(guess);
   float nq = td_value(guess, reward, max_next, done, lr, gamma);
+  if (mode == kTdStorePlain) { *addr = f32_bits(nq); return nq; }
   if (mode == kTdStoreSc1) {
     __hip_atomic_store(addr, f32_bits(nq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return nq;
   }
-  if (mode == kTdStorePlain) { *addr = f32_bits(nq); return nq; }
   if (mode == kTdStoreNt) { __builtin_nontemporal_store(f32_bits(nq), addr); return nq; }
   if (mode == kTdNone) return nq;
   if (mode == kTdAdd) { atomicAdd(&slot->q[a], nq - guess); return nq; }
@@ -142,16 +271,17 @@ __device__ __forceinline__ float td_update(q2048_slot* slot, int a, float guess,
   atomicAdd(&slot->q[a], nq - bits_f32(expect));  // extreme contention: keep the sample
   return nq;
 }
-
-__device__ __forceinline__ u64 state_key(const Board& b, u64 salt, uint32_t* status) {
-  bool ov;
-  u64 k = pack_key(b, ov) ^ salt;
-  if (ov) atomicOr(status, Q2048_STATUS_TILE_OVERFLOW);
-  return k == 0ull ? 1ull : k;  // 0 marks an empty slot
+__device__ __forceinline__ uint32_t td_mode_of(uint32_t flags) {
+  const uint32_t x = (flags >> 8) & 15u;  // experiment bits (not ABI)
+  return x ? x : ((flags & Q2048_FLAG_TD_CAS) ? kTdCas : kTdStorePlain);
 }
 
 __device__ __forceinline__ uint32_t wave_count(bool pred) {
   return (uint32_t)__popcll(__ballot(pred));
+}
+__device__ __forceinline__ bool wave_leader() {  // first active lane of the wave
+  const u64 active = __ballot(true);
+  return (u64)(threadIdx.x & 63) == (u64)__ffsll((long long)active) - 1ull;
 }
 
 // block-level statistics staging (LDS) and flush
@@ -182,62 +312,72 @@ __device__ __forceinline__ void episode_stats(BlockStats& s, const Aux& a, uint3
 // ---------------------------------------------------------------------------------------------
 // env kernels
 // ---------------------------------------------------------------------------------------------
+template <int N>
 __global__ __launch_bounds__(kBlock) void k_env_init(uint8_t* boards, q2048_aux* aux, int64_t B,
                                                      uint64_t seed, uint64_t env_id0) {
+  __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= B) return;
-  Board b; Aux a;
+  typename Geo<N>::BoardT b;
+  Aux a;
   init_env(b, a, seed, env_id0 + (uint64_t)i);
-  st_board(boards, i, b);
-  st_aux(aux, i, a);
+  store_board(boards, i, B, b, st);
+  if (i < B) st_aux(aux, i, a);
 }
 
+template <int N>
 __global__ __launch_bounds__(kBlock) void k_env_reset(uint8_t* boards, q2048_aux* aux,
                                                       const uint8_t* mask, int64_t B, uint64_t seed,
                                                       uint64_t env_id0) {
+  __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= B) return;
-  if (mask != nullptr && mask[i] == 0) return;
-  Board b = ld_board(boards, i);
-  Aux a = ld_aux(aux, i);
-  begin_episode(b, a, seed, env_id0 + (uint64_t)i);
-  st_board(boards, i, b);
-  st_aux(aux, i, a);
+  auto b = load_board(boards, i, B, st);
+  if (i < B && (mask == nullptr || mask[i] != 0)) {
+    Aux a = ld_aux(aux, i);
+    begin_episode(b, a, seed, env_id0 + (uint64_t)i);
+    st_aux(aux, i, a);
+  }
+  store_board(boards, i, B, b, st);
 }
 
+template <int N>
 __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux* aux,
                                                      const uint8_t* actions, int64_t B, uint64_t seed,
                                                      uint64_t env_id0, uint32_t ctr, float* reward,
                                                      uint8_t* done, uint8_t* max_l2, uint32_t* status,
                                                      const uint32_t* draw_pos, const uint32_t* draw_val) {
+  __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= B) return;
-  const int act = actions[i];
-  if (act > 3) {  // rejected, never masked (Game2048_env.py:56-60 would mis-rotate)
-    atomicOr(status, Q2048_STATUS_BAD_ACTION);
-    reward[i] = 0.f; done[i] = 0; max_l2[i] = 0;
-    return;
+  auto b = load_board(boards, i, B, st);
+  if (i < B) {
+    const int act = actions[i];
+    if (act > 3) {  // rejected, never masked (Game2048_env.py:56-60 would mis-rotate)
+      atomicOr(status, Q2048_STATUS_BAD_ACTION);
+      reward[i] = 0.f; done[i] = 0; max_l2[i] = 0;
+    } else {
+      Aux a = ld_aux(aux, i);
+      Draws x;
+      if (draw_pos != nullptr) { x.x2 = draw_pos[i]; x.x3 = draw_val[i]; }  // injected (parity tests)
+      else x = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamStep);
+      const StepOut o = env_step(b, a, act, x.x2, x.x3);
+      st_aux(aux, i, a);
+      reward[i] = o.reward; done[i] = o.done; max_l2[i] = o.max_log2;
+    }
   }
-  Board b = ld_board(boards, i);
-  Aux a = ld_aux(aux, i);
-  Draws x;
-  if (draw_pos != nullptr) { x.x2 = draw_pos[i]; x.x3 = draw_val[i]; }  // injected (parity tests)
-  else x = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamStep);
-  const StepOut o = env_step(b, a, act, x.x2, x.x3);
-  st_board(boards, i, b);
-  st_aux(aux, i, a);
-  reward[i] = o.reward; done[i] = o.done; max_l2[i] = o.max_log2;
+  store_board(boards, i, B, b, st);
 }
 
 // ---------------------------------------------------------------------------------------------
 // agent kernels
 // ---------------------------------------------------------------------------------------------
+template <int N>
 __global__ __launch_bounds__(kBlock) void k_q_choose(const q2048_slot* table, u64 mask,
                                                      const uint8_t* boards, int64_t B, double eps,
                                                      uint64_t seed, uint64_t env_id0, uint32_t ctr,
                                                      uint32_t flags, uint8_t* actions, uint32_t* status,
                                                      const uint32_t* draw_eps, const uint32_t* draw_act) {
+  __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const auto b = load_board(boards, i, B, st);
   if (i >= B) return;
   const uint64_t id = env_id0 + (uint64_t)i;
   const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
@@ -249,61 +389,43 @@ __global__ __launch_bounds__(kBlock) void k_q_choose(const q2048_slot* table, u6
     act = draw_action(x.x1);
   } else {
     Row r;
-    probe_find(table, mask, state_key(ld_board(boards, i), salt, status), r);
+    bool made;
+    probe_find(table, mask, state_key(b, salt, status), r, made);
     act = argmax4(r.q0, r.q1, r.q2, r.q3);
   }
   actions[i] = (uint8_t)act;
 }
 
+template <int N>
 __global__ __launch_bounds__(kBlock) void k_q_lookup(const q2048_slot* table, u64 mask,
                                                      const uint8_t* boards, int64_t B, uint64_t env_id0,
-                                                     uint32_t flags, float* q_out, uint8_t* found) {
+                                                     uint32_t flags, float* q_out, uint8_t* found,
+                                                     uint32_t* status) {
+  __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const auto b = load_board(boards, i, B, st);
   if (i >= B) return;
   const uint64_t id = (flags & Q2048_FLAG_SINGLE_ENV) ? env_id0 : env_id0 + (uint64_t)i;
   const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
-  bool ov;
-  u64 key = pack_key(ld_board(boards, i), ov) ^ salt;
-  key = key == 0ull ? 1ull : key;
   Row r;
-  const int64_t slot = probe_find(table, mask, key, r);
+  bool made;
+  const int64_t slot = probe_find(table, mask, state_key(b, salt, status), r, made);
   reinterpret_cast<float4*>(q_out)[i] = make_float4(r.q0, r.q1, r.q2, r.q3);
   if (found != nullptr) found[i] = slot >= 0;
 }
 
-// A row claim in flight: the compare-and-swap was issued, its result is consumed later, so the
-// round trip hides behind the next step's arithmetic.
-struct Claim { u64 ret; u64 at; bool active; };
-
-__device__ __forceinline__ void claim_issue(q2048_slot* table, int64_t slot, u64 key, Claim& c) {
-  c.active = slot < 0 && slot != kNoSlot;
-  if (c.active) {
-    c.at = (u64)~slot;
-    c.ret = atomicCAS(reinterpret_cast<u64*>(&table[c.at].key), 0ull, key);
-  }
-}
-__device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, u64 key, Claim& c,
-                                                 int64_t slot, bool& inserted) {
-  if (!c.active) return slot;
-  c.active = false;
-  if (c.ret == 0ull) { inserted = true; return (int64_t)c.at; }
-  if (c.ret == key) return (int64_t)c.at;
-  return probe_insert(table, mask, key, c.at + 1ull, inserted);  // another key took the slot
-}
-
-__device__ __forceinline__ uint32_t td_mode_of(uint32_t flags) {
-  const uint32_t x = (flags >> 8) & 15u;  // experiment bits (not ABI)
-  return x ? x : ((flags & Q2048_FLAG_TD_CAS) ? kTdCas : kTdStorePlain);
-}
-
+template <int N>
 __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask, const uint8_t* s,
                                                      const uint8_t* actions, const float* reward,
                                                      const uint8_t* s2, const uint8_t* done, int64_t B,
                                                      double lr, double gamma, uint64_t env_id0,
                                                      uint32_t flags, int64_t* stats_i, uint32_t* status) {
   __shared__ BlockStats bs;
+  __shared__ Stage<N> st;
   stats_clear(bs);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const auto b_s = load_board(s, i, B, st);
+  const auto b_n = load_board(s2, i, B, st);
   if (i < B) {
     const int act = actions[i];
     bool ins_n = false, ins_s = false, dropped = false;
@@ -312,16 +434,16 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
       atomicOr(status, Q2048_STATUS_BAD_ACTION);
     } else {
       const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(env_id0 + (uint64_t)i) : 0ull;
-      const u64 key_s = state_key(ld_board(s, i), salt, status);
-      const u64 key_n = state_key(ld_board(s2, i), salt, status);
+      const auto key_s = state_key(b_s, salt, status);
+      const auto key_n = state_key(b_n, salt, status);
       // q_table[next_state] (Agent/main.py:41): the defaultdict creates the row, so do we
       Row rn;
-      const int64_t slot_n = probe_find(table, mask, key_n, rn);
+      const int64_t slot_n = probe_find(table, mask, key_n, rn, ins_n);
       if (slot_n < 0 && slot_n != kNoSlot) probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
       const float max_next = max4(rn.q0, rn.q1, rn.q2, rn.q3);
       // q_table[state][action] (:43)
       Row rs;
-      int64_t slot = probe_find(table, mask, key_s, rs);
+      int64_t slot = probe_find(table, mask, key_s, rs, ins_s);
       if (slot < 0 && slot != kNoSlot) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
       if (slot >= 0) {
         td_update(&table[slot], act, row_get(rs, act), reward[i], max_next, done[i] != 0, lr, gamma,
@@ -333,8 +455,7 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
     }
     const uint32_t n_ins = wave_count(ins_n) + wave_count(ins_s), n_drop = wave_count(dropped);
     if (retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)retries);
-    const u64 active = __ballot(true);  // the first active lane publishes the wave's ballots
-    if ((u64)(threadIdx.x & 63) == (u64)__ffsll((long long)active) - 1ull) {
+    if (wave_leader()) {
       if (n_ins) atomicAdd(&bs.i[Q2048_ST_INSERTS], (u64)n_ins);
       if (n_drop) atomicAdd(&bs.i[Q2048_ST_DROPS], (u64)n_drop);
     }
@@ -347,32 +468,36 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
 //
 // Per step and lane the table sees: one probe of the next state (a read), at most one row claim
 // (compare-and-swap on the key word, only for a state reached for the first time) and one
-// 4-byte write of Q[s][a].  The claim of s' is issued as soon as the probe finds it absent and
-// consumed one step later, when s' has become s: its round trip overlaps the next step's
-// arithmetic.  Rows therefore appear exactly when the reference's defaultdict creates them
-// (q_table[next_state] / q_table[state] in update_q_value, Agent/main.py:41-43).
+// 4-byte write of Q[s][a].  On 4x4 the claim of s' is issued as soon as the probe finds it
+// absent and consumed one step later, when s' has become s.  Rows appear exactly when the
+// reference's defaultdict creates them (q_table[next_state] / q_table[state] in
+// update_q_value, Agent/main.py:41-43).
 // ---------------------------------------------------------------------------------------------
+template <int N>
 __global__ __launch_bounds__(kBlock) void k_fused_rollout(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
     double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
     int64_t* stats_i, double* stats_f, uint32_t* status) {
   __shared__ BlockStats bs;
+  __shared__ Stage<N> st;
   stats_clear(bs);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  auto b = load_board(boards, i, B, st);
   if (i < B) {
     const uint64_t id = env_id0 + (uint64_t)i;
     const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
     const uint32_t td_mode = td_mode_of(flags);
     // experiment bits (not ABI): 12 no row creation, 13 no next-state probe
     const bool x_noclaim = (flags >> 12) & 1u, x_noprobe = (flags >> 13) & 1u;
-    Board b = ld_board(boards, i);
     Aux a = ld_aux(aux, i);
-    u64 key_s = state_key(b, salt, status);
+    auto key_s = state_key(b, salt, status);
     Row q;
-    int64_t slot_s = probe_find(table, mask, key_s, q);
+    bool made0 = false;
+    int64_t slot_s = probe_find(table, mask, key_s, q, made0);
     Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
-    uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = 0, n_drop = 0, retries = 0;
+    uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = wave_count(made0), n_drop = 0;
+    uint32_t retries = 0;
     double reward_sum = 0.0;
 
     for (int t = 0; t < steps; ++t) {
@@ -380,8 +505,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
       bool explored;
       const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);  // main.py:92
       const StepOut o = env_step(b, a, act, x.x2, x.x3);                               // :93
-      const u64 key_n = state_key(b, salt, status);                                    // :94
-      const bool same = key_n == key_s;
+      const auto key_n = state_key(b, salt, status);                                   // :94
+      const bool same = key_eq(key_n, key_s);
       // the row of s: claimed one step ago (in flight since), or now if s opened the episode/launch
       bool ins_s = false, ins_n = false;
       slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_s);
@@ -391,8 +516,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
       Row qn = q;
       int64_t slot_n = slot_s;
       if (!same) {
-        if (x_noprobe) { qn = Row{0.f, 0.f, 0.f, 0.f}; slot_n = ~(int64_t)(mix64(key_n) & mask); }
-        else slot_n = probe_find(table, mask, key_n, qn);
+        if (x_noprobe) { qn = Row{0.f, 0.f, 0.f, 0.f}; slot_n = ~(int64_t)key_home(key_n, mask); }
+        else slot_n = probe_find(table, mask, key_n, qn, ins_n);
       }
       const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
       float nq = 0.f;
@@ -407,13 +532,19 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
         episode_stats(bs, a, o.max_log2);
         begin_episode(b, a, seed, id);                                                 // :81
         key_s = state_key(b, salt, status);
-        slot_s = probe_find(table, mask, key_s, q);
+        bool made = false;
+        slot_s = probe_find(table, mask, key_s, q, made);
+        ins_n = ins_n || made;
       } else if (same) {            // invalid move: same state, its row just changed (:100)
         if (updated) row_set(q, act, nq);
         else slot_s = kNoSlot;      // dropped: do not retry the claim with a stale hint
       } else {
         key_s = key_n; slot_s = slot_n; q = qn;                                        // :100
-        if (!x_noclaim) claim_issue(table, slot_s, key_s, claim);
+        if (!x_noclaim) {
+          bool made = false;
+          slot_s = claim_issue(table, mask, slot_s, key_s, claim, made);
+          ins_n = ins_n || made;
+        }
       }
       n_valid += wave_count(o.valid != 0);
       n_explore += wave_count(explored);
@@ -425,15 +556,14 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
     bool ins_last = false;  // the claim issued by the last step (its row belongs to the dict too)
     claim_resolve(table, mask, key_s, claim, slot_s, ins_last);
     n_insert += wave_count(ins_last);
-    st_board(boards, i, b);
     st_aux(aux, i, a);
 
     if (n_drop) atomicOr(status, Q2048_STATUS_TABLE_FULL);
     if (retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)retries);
     atomicAdd(&bs.f[Q2048_SF_REWARD], reward_sum);
-    const u64 active = __ballot(true);
-    if ((u64)(threadIdx.x & 63) == (u64)__ffsll((long long)active) - 1ull) {
-      atomicAdd(&bs.i[Q2048_ST_STEPS], (u64)__popcll(active) * (u64)steps);
+    const uint32_t n_active = wave_count(true);
+    if (wave_leader()) {
+      atomicAdd(&bs.i[Q2048_ST_STEPS], (u64)n_active * (u64)steps);
       atomicAdd(&bs.i[Q2048_ST_VALID], (u64)n_valid);
       atomicAdd(&bs.i[Q2048_ST_EXPLORE], (u64)n_explore);
       atomicAdd(&bs.i[Q2048_ST_EPISODES], (u64)n_done);
@@ -441,6 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
       atomicAdd(&bs.i[Q2048_ST_DROPS], (u64)n_drop);
     }
   }
+  store_board(boards, i, B, b, st);
   stats_flush(bs, stats_i, stats_f);
 }
 
@@ -449,14 +580,15 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_table_export(const q2048_slot* table, u64 cap,
                                                          u64* keys_out, float* q_out, int64_t max_rows,
-                                                         u64* count) {
+                                                         int key_words, u64* count) {
   const u64 stride = (u64)gridDim.x * kBlock;
   for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < cap; i += stride) {
     const u64 k = table[i].key;
     if (k == 0ull) continue;
     const u64 at = atomicAdd(count, 1ull);
     if (keys_out != nullptr && (int64_t)at < max_rows) {
-      keys_out[at] = k;
+      keys_out[at * (u64)key_words] = k;
+      if (key_words == 2) keys_out[at * 2ull + 1ull] = table[i].reserved;
       reinterpret_cast<float4*>(q_out)[at] =
           make_float4(table[i].q[0], table[i].q[1], table[i].q[2], table[i].q[3]);
     }
@@ -470,7 +602,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline unsigned grid_for(int64_t B) { return (unsigned)((B + kBlock - 1) / kBlock); }
 inline int launch_status() { return hipGetLastError() == hipSuccess ? Q2048_OK : Q2048_ERR_LAUNCH; }
 inline int check_batch(int64_t B, int n) {
-  if (n != 4) return Q2048_ERR_UNSUPPORTED;
+  if (n != 4 && n != 5) return Q2048_ERR_UNSUPPORTED;
   if (B < 0 || B > ((int64_t)1 << 40)) return Q2048_ERR_SIZE;
   return Q2048_OK;
 }
@@ -480,6 +612,16 @@ inline int check_table(const void* table, int cap_log2) {
   if (!aligned16(table)) return Q2048_ERR_ALIGN;
   return Q2048_OK;
 }
+// launches kernel<4> or kernel<5>
+#define Q2048_LAUNCH(kernel, n, B, stream, ...)                                                   \
+  do {                                                                                            \
+    if ((n) == 4)                                                                                 \
+      hipLaunchKernelGGL(kernel<4>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)(stream),    \
+                         __VA_ARGS__);                                                            \
+    else                                                                                          \
+      hipLaunchKernelGGL(kernel<5>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)(stream),    \
+                         __VA_ARGS__);                                                            \
+  } while (0)
 }  // namespace
 
 extern "C" {
@@ -492,9 +634,9 @@ const char* q2048_strerror(int code) {
   switch (code) {
     case Q2048_OK: return "ok";
     case Q2048_ERR_NULL: return "a required pointer is NULL";
-    case Q2048_ERR_SIZE: return "size out of range (batch, steps or cap_log2)";
+    case Q2048_ERR_SIZE: return "size out of range (batch, steps, cap_log2 or key_words)";
     case Q2048_ERR_ALIGN: return "boards/aux/table must be 16-byte aligned";
-    case Q2048_ERR_UNSUPPORTED: return "unsupported board side (only n == 4)";
+    case Q2048_ERR_UNSUPPORTED: return "unsupported board side (n must be 4 or 5)";
     case Q2048_ERR_LAUNCH: return "HIP launch failed";
     case Q2048_ERR_RANGE: return "scalar out of range (eps in [0,1], lr and gamma finite)";
     default: return "unknown error";
@@ -507,8 +649,7 @@ int q2048_env_init(uint8_t* boards, q2048_aux* aux, int64_t B, int n, uint64_t s
   if (boards == nullptr || aux == nullptr) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
-  hipLaunchKernelGGL(k_env_init, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, boards,
-                     aux, B, seed, env_id0);
+  Q2048_LAUNCH(k_env_init, n, B, stream, boards, aux, B, seed, env_id0);
   return launch_status();
 }
 
@@ -518,8 +659,7 @@ int q2048_env_reset(uint8_t* boards, q2048_aux* aux, const uint8_t* mask, int64_
   if (boards == nullptr || aux == nullptr) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
-  hipLaunchKernelGGL(k_env_reset, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, boards,
-                     aux, mask, B, seed, env_id0);
+  Q2048_LAUNCH(k_env_reset, n, B, stream, boards, aux, mask, B, seed, env_id0);
   return launch_status();
 }
 
@@ -531,9 +671,8 @@ static int env_step_impl(uint8_t* boards, q2048_aux* aux, const uint8_t* actions
   if (!boards || !aux || !actions || !reward || !done || !max_log2 || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
-  hipLaunchKernelGGL(k_env_step, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, boards,
-                     aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status, draw_pos,
-                     draw_val);
+  Q2048_LAUNCH(k_env_step, n, B, stream, boards, aux, actions, B, seed, env_id0, ctr, reward, done,
+               max_log2, status, draw_pos, draw_val);
   return launch_status();
 }
 
@@ -563,9 +702,8 @@ static int q_choose_impl(const q2048_slot* table, int cap_log2, const uint8_t* b
   if (!aligned16(boards)) return Q2048_ERR_ALIGN;
   if (!(eps >= 0.0 && eps <= 1.0)) return Q2048_ERR_RANGE;
   if (B == 0) return Q2048_OK;
-  hipLaunchKernelGGL(k_q_choose, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
-                     (u64)((1ull << cap_log2) - 1ull), boards, B, eps, seed, env_id0, ctr, flags,
-                     actions, status, draw_eps, draw_act);
+  Q2048_LAUNCH(k_q_choose, n, B, stream, table, (u64)((1ull << cap_log2) - 1ull), boards, B, eps,
+               seed, env_id0, ctr, flags, actions, status, draw_eps, draw_act);
   return launch_status();
 }
 
@@ -595,21 +733,21 @@ int q2048_q_update(q2048_slot* table, int cap_log2, const uint8_t* boards_s, con
   if (!aligned16(boards_s) || !aligned16(boards_s2)) return Q2048_ERR_ALIGN;
   if (!(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
   if (B == 0) return Q2048_OK;
-  hipLaunchKernelGGL(k_q_update, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
-                     (u64)((1ull << cap_log2) - 1ull), boards_s, actions, reward, boards_s2, done, B,
-                     lr, gamma, env_id0, flags, stats_i, status);
+  Q2048_LAUNCH(k_q_update, n, B, stream, table, (u64)((1ull << cap_log2) - 1ull), boards_s, actions,
+               reward, boards_s2, done, B, lr, gamma, env_id0, flags, stats_i, status);
   return launch_status();
 }
 
 int q2048_q_lookup(const q2048_slot* table, int cap_log2, const uint8_t* boards, int64_t B, int n,
-                   uint64_t env_id0, uint32_t flags, float* q_out, uint8_t* found, void* stream) {
+                   uint64_t env_id0, uint32_t flags, float* q_out, uint8_t* found, uint32_t* status,
+                   void* stream) {
   if (int e = check_batch(B, n)) return e;
   if (int e = check_table(table, cap_log2)) return e;
-  if (!boards || !q_out) return Q2048_ERR_NULL;
+  if (!boards || !q_out || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(q_out)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
-  hipLaunchKernelGGL(k_q_lookup, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
-                     (u64)((1ull << cap_log2) - 1ull), boards, B, env_id0, flags, q_out, found);
+  Q2048_LAUNCH(k_q_lookup, n, B, stream, table, (u64)((1ull << cap_log2) - 1ull), boards, B, env_id0,
+               flags, q_out, found, status);
   return launch_status();
 }
 
@@ -624,27 +762,27 @@ int q2048_fused_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int 
   if (steps < 0 || steps > (1 << 30)) return Q2048_ERR_SIZE;
   if (!(eps >= 0.0 && eps <= 1.0) || !(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
   if (B == 0 || steps == 0) return Q2048_OK;
-  hipLaunchKernelGGL(k_fused_rollout, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream,
-                     boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B, (int)steps, eps, lr,
-                     gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status);
+  Q2048_LAUNCH(k_fused_rollout, n, B, stream, boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B,
+               (int)steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status);
   return launch_status();
 }
 
 int q2048_table_count(const q2048_slot* table, int cap_log2, int64_t* count, void* stream) {
-  return q2048_table_export(table, cap_log2, nullptr, nullptr, 0, count, stream);
+  return q2048_table_export(table, cap_log2, nullptr, nullptr, 0, 1, count, stream);
 }
 
 int q2048_table_export(const q2048_slot* table, int cap_log2, uint64_t* keys_out, float* q_out,
-                       int64_t max_rows, int64_t* count, void* stream) {
+                       int64_t max_rows, int key_words, int64_t* count, void* stream) {
   if (int e = check_table(table, cap_log2)) return e;
   if (count == nullptr) return Q2048_ERR_NULL;
   if ((keys_out == nullptr) != (q_out == nullptr) || max_rows < 0) return Q2048_ERR_SIZE;
+  if (key_words != 1 && key_words != 2) return Q2048_ERR_SIZE;
   if (q_out != nullptr && !aligned16(q_out)) return Q2048_ERR_ALIGN;
   const u64 cap = 1ull << cap_log2;
   const u64 blocks = (cap + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(k_table_export, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0,
                      (hipStream_t)stream, table, cap, reinterpret_cast<u64*>(keys_out), q_out,
-                     max_rows, reinterpret_cast<u64*>(count));
+                     max_rows, key_words, reinterpret_cast<u64*>(count));
   return launch_status();
 }
 

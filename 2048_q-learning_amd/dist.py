@@ -58,7 +58,9 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # Q2048_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a 1-GPU box)
+            backend = os.environ.get("Q2048_DIST_BACKEND") or (
+                "nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)

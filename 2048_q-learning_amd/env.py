@@ -42,9 +42,9 @@ def _require_gpu(device) -> torch.device:
 
 
 class BatchedGame2048Env:
-    """B independent 4x4 boards, one per GPU lane.
+    """B independent boards (4x4, or 5x5 with board_size=5), one per GPU lane.
 
-    boards  torch.uint8 [B, 16]  log2 tiles, row-major (0 empty, k = tile 2^k)
+    boards  torch.uint8 [B, n*n] log2 tiles, row-major (0 empty, k = tile 2^k)
     aux     torch.uint8 [B, 16]  q2048_aux records (score, return, previous_max, streak, episode)
 
     Lane i is global env `env_id0 + i`; its random draws depend only on (seed, global id,
@@ -53,23 +53,24 @@ class BatchedGame2048Env:
     def __init__(self, num_envs: int, board_size: int = 4, device="cuda", seed: int = 0,
                  env_id0: int = 0):
         self.device = _require_gpu(device)
-        if board_size != 4:
-            raise NotImplementedError("board_size 5 is a later round; only 4x4 is implemented")
+        if board_size not in (4, 5):
+            raise NotImplementedError("board_size must be 4 (the reference) or 5")
         if num_envs <= 0:
             raise ValueError("num_envs must be positive")
-        self.num_envs, self.board_size = int(num_envs), 4
+        self.num_envs, self.board_size = int(num_envs), int(board_size)
+        self.cells = self.board_size * self.board_size
         self.seed, self.env_id0 = int(seed), int(env_id0)
         self.ctr = 0  # global step counter = counter word of the step draws
         self.action_space = _Discrete(4)                                 # Game2048_env.py:89
         B = self.num_envs
-        self.boards = torch.empty((B, 16), dtype=torch.uint8, device=self.device)
+        self.boards = torch.empty((B, self.cells), dtype=torch.uint8, device=self.device)
         self.aux = torch.empty((B, 16), dtype=torch.uint8, device=self.device)
         self._reward = torch.empty(B, dtype=torch.float32, device=self.device)
         self._done = torch.empty(B, dtype=torch.uint8, device=self.device)
         self._max = torch.empty(B, dtype=torch.uint8, device=self.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        N.check(N.lib().q2048_env_init(_ptr(self.boards), _ptr(self.aux), B, 4, self.seed,
-                                       self.env_id0, _stream(self.device)), "env_init")
+        N.check(N.lib().q2048_env_init(_ptr(self.boards), _ptr(self.aux), B, self.board_size,
+                                       self.seed, self.env_id0, _stream(self.device)), "env_init")
 
     # -- reference surface ---------------------------------------------------------------
     def reset(self, mask: torch.Tensor | None = None) -> torch.Tensor:
@@ -77,7 +78,7 @@ class BatchedGame2048Env:
         if mask is not None:
             mask = self._as_u8(mask, "mask")
         N.check(N.lib().q2048_env_reset(_ptr(self.boards), _ptr(self.aux), _ptr(mask),
-                                        self.num_envs, 4, self.seed, self.env_id0,
+                                        self.num_envs, self.board_size, self.seed, self.env_id0,
                                         _stream(self.device)), "env_reset")
         return self.boards
 
@@ -86,7 +87,7 @@ class BatchedGame2048Env:
         max_tile[B] int32 raw tile value, the reference's `info`)."""
         actions = self._as_u8(actions, "actions")
         N.check(N.lib().q2048_env_step(
-            _ptr(self.boards), _ptr(self.aux), _ptr(actions), self.num_envs, 4, self.seed,
+            _ptr(self.boards), _ptr(self.aux), _ptr(actions), self.num_envs, self.board_size, self.seed,
             self.env_id0, self.ctr & 0xFFFFFFFF, _ptr(self._reward), _ptr(self._done),
             _ptr(self._max), _ptr(self.status), _stream(self.device)), "env_step")
         self.ctr += 1
@@ -137,15 +138,17 @@ AUX_DTYPE = np.dtype([("score", "<i4"), ("ep_return", "<f4"), ("prev_max", "u1")
 
 
 def boards_to_raw(boards_log2) -> np.ndarray:
-    """uint8 log2 boards [...,16] -> np.int64 raw tile values [...,4,4] (reference layout)."""
+    """uint8 log2 boards [..., n*n] -> np.int64 raw tile values [..., n, n] (reference layout)."""
     b = np.asarray(boards_log2, dtype=np.int64)
-    return np.where(b > 0, np.left_shift(1, b), 0).reshape(b.shape[:-1] + (4, 4))
+    n = int(round(b.shape[-1] ** 0.5))
+    return np.where(b > 0, np.left_shift(1, b), 0).reshape(b.shape[:-1] + (n, n))
 
 
 def raw_to_boards(raw) -> np.ndarray:
-    """Reference boards (raw tile values, any nesting of 4x4) -> uint8 log2 [...,16]."""
+    """Reference boards (raw tile values, any nesting of n x n) -> uint8 log2 [..., n*n]."""
     r = np.asarray(raw, dtype=np.int64)
-    r = r.reshape(r.shape[:-2] + (16,)) if r.shape[-2:] == (4, 4) else r
+    if r.ndim >= 2 and r.shape[-1] == r.shape[-2] and r.shape[-1] in (4, 5):
+        r = r.reshape(r.shape[:-2] + (r.shape[-1] * r.shape[-1],))
     out = np.zeros(r.shape, dtype=np.uint8)
     nz = r > 0
     lg = np.zeros(r.shape, dtype=np.int64)

@@ -34,6 +34,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 ALGO_BYTES_FUSED_4X4 = 122  # SURVEY.md section 8(d) / BASELINE.md section 4
+ALGO_BYTES_FUSED_5X5 = 156
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 
@@ -44,6 +45,7 @@ def parse_args():
     p.add_argument("--steps", type=int, default=256)
     p.add_argument("--warmup", type=int, default=64)
     p.add_argument("--boards-per-gpu", type=int, default=1 << 20)
+    p.add_argument("--board-size", type=int, default=4, help="4 (BASELINE configs[2]/[3]) or 5 (configs[4])")
     p.add_argument("--steps-per-launch", type=int, default=64,
                    help="env steps per fused launch (boards stay in registers in between)")
     p.add_argument("--eps", type=float, default=0.95)
@@ -119,7 +121,7 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())  # 1 rank = 1 GPU on a node
     torch.cuda.set_device(dev)
 
     B = args.boards_per_gpu
@@ -127,11 +129,13 @@ def main():
     S = max(1, min(args.steps_per_launch, args.steps))
     cap_log2 = args.cap_log2 or table_capacity_log2(B, args.steps + args.warmup)
 
-    env = pkg.BatchedGame2048Env(shard.num_envs, seed=args.seed, env_id0=shard.env_id0, device=dev)
+    algo_bytes = ALGO_BYTES_FUSED_4X4 if args.board_size == 4 else ALGO_BYTES_FUSED_5X5
+    env = pkg.BatchedGame2048Env(shard.num_envs, board_size=args.board_size, seed=args.seed,
+                                 env_id0=shard.env_id0, device=dev)
     agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
                                       exploration_rate=args.eps, capacity_log2=cap_log2,
                                       seed=args.seed, env_id0=shard.env_id0, device=dev,
-                                      strict_td=args.strict_td)
+                                      strict_td=args.strict_td, board_size=args.board_size)
 
     def run(steps):
         launches = 0
@@ -144,6 +148,7 @@ def main():
         return launches
 
     run(args.warmup)                       # mid-game boards, warm table (untimed)
+    pkg.dist.allreduce_stats(agent.stats_i, agent.stats_f)   # untimed: RCCL builds its rings lazily
     agent.stats(reset=True)
     torch.cuda.synchronize(dev)
     pkg.dist.barrier()
@@ -170,18 +175,18 @@ def main():
 
     # roofline of the dominant kernel, per launch, on this rank
     avg_launch_s = (kernel_ms_max / 1e3) / launches
-    algo_bytes_per_launch = ALGO_BYTES_FUSED_4X4 * shard.num_envs * (args.steps / launches)
+    algo_bytes_per_launch = algo_bytes * shard.num_envs * (args.steps / launches)
     achieved = algo_bytes_per_launch / avg_launch_s / 1e9
     roofline = {"bound": "hbm", "kernel": "k_fused_rollout", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                 "traffic": None,  # filled below from the committed PMC passes
-                "algorithmic_bytes_per_env_step": ALGO_BYTES_FUSED_4X4,
+                "algorithmic_bytes_per_env_step": algo_bytes,
                 "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                 "note": f"register-resident, K={S} env steps per launch: boards/aux cross HBM once "
                         f"per launch, the figure counts them once per step (SURVEY 8(d))"}
 
-    pmc = pmc_traffic_per_env_step()
+    pmc = pmc_traffic_per_env_step() if args.board_size == 4 else None
     if pmc is not None:
         roofline["traffic"] = pmc["bytes_per_env_step"] * shard.num_envs * (args.steps / launches)
         roofline["traffic_source"] = pmc["source"]
@@ -191,8 +196,9 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_max * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"{B} parallel 4x4 boards per GPU (uint8 log2), device open-addressed "
-                               f"hash Q-table, fused step+select+TD kernel (BASELINE configs[2]"
+        "config": {"workload": f"{B} parallel {args.board_size}x{args.board_size} boards per GPU (uint8 "
+                               f"log2), device open-addressed hash Q-table, fused step+select+TD kernel "
+                               f"(BASELINE configs[{2 if args.board_size == 4 else 4}]"
                                f"{'' if world == 1 else '/[3] sharded, one Q replica per GPU'})",
                    "boards_per_gpu": B, "total_boards": shard.total_envs,
                    "steps_per_launch": S, "table_capacity_log2": cap_log2,

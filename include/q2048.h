@@ -26,8 +26,9 @@
  *   - return   0 on success, a negative Q2048_ERR_* otherwise (argument errors are detected
  *              on the host before anything is launched).  Data-dependent conditions are
  *              reported through the device `status` word (Q2048_STATUS_* bits, OR-ed).
- *   - n        board side.  This round implements n == 4; other values return
- *              Q2048_ERR_UNSUPPORTED.
+ *   - n        board side, 4 or 5 (other values return Q2048_ERR_UNSUPPORTED).  The reference
+ *              hard-codes 4 (Game2048_env.py:12,41); 5 is the same algorithm on uint8[B][25]
+ *              boards (unpadded) with a 125-bit state key held in `key` + `reserved`.
  */
 #ifndef Q2048_H
 #define Q2048_H
@@ -46,7 +47,7 @@ extern "C" {
 #define Q2048_ERR_NULL (-1)        /* a required pointer is NULL */
 #define Q2048_ERR_SIZE (-2)        /* negative batch / steps, bad cap_log2 */
 #define Q2048_ERR_ALIGN (-3)       /* boards / aux / table not 16-byte aligned */
-#define Q2048_ERR_UNSUPPORTED (-4) /* board side other than 4 */
+#define Q2048_ERR_UNSUPPORTED (-4) /* board side other than 4 or 5 */
 #define Q2048_ERR_LAUNCH (-5)      /* the HIP runtime refused the launch */
 #define Q2048_ERR_RANGE (-6)       /* a scalar is outside its domain (eps, lr, gamma) */
 
@@ -74,9 +75,11 @@ typedef struct q2048_aux {
 
 /* one row of the Q-table: q_table[state] -> 4 floats (Agent/main.py:16) */
 typedef struct q2048_slot {
-  uint64_t key;      /* 16 log2 nibbles, cell 0 in the low nibble; 0 = empty slot */
+  uint64_t key;      /* 4x4: 16 log2 nibbles, cell 0 in the low nibble.  5x5: bits 0..62 of the 125-bit
+                        key (25 cells x 5 bits) | bit 63.  0 = empty slot */
   float q[4];        /* Q(s, a), a = 0 left, 1 up, 2 right, 3 down */
-  uint64_t reserved; /* keeps rows 32-byte aligned (never straddles a 64-byte line) */
+  uint64_t reserved; /* 4x4: 0 (keeps rows 32-byte aligned: a row never straddles a 64-byte line).
+                        5x5: bits 63..124 of the key | bit 63, published right after `key` */
 } q2048_slot;
 
 /* indices of the statistics vectors (device int64[Q2048_NSTAT_I], double[Q2048_NSTAT_F]);
@@ -159,7 +162,7 @@ int q2048_q_update(q2048_slot *table, int cap_log2, const uint8_t *boards_s,
  * found[B] (may be NULL). */
 int q2048_q_lookup(const q2048_slot *table, int cap_log2, const uint8_t *boards, int64_t B,
                    int n, uint64_t env_id0, uint32_t flags, float *q_out, uint8_t *found,
-                   void *stream);
+                   uint32_t *status, void *stream);
 
 /* The loop body of Agent/main.py:91-101 + the reset of :81, `steps` times for B envs in ONE
  * launch: choose -> step -> update -> accumulate -> (on done) statistics and reset.  Boards,
@@ -176,9 +179,10 @@ int q2048_table_count(const q2048_slot *table, int cap_log2, int64_t *count, voi
 
 /* Export occupied rows (for conversion to the reference's dict{state -> 4 floats},
  * Agent/main.py:16): writes up to max_rows (key, q[4]) pairs in unspecified order and adds the
- * number of occupied slots to *count (rows beyond max_rows are counted, not written). */
+ * number of occupied slots to *count (rows beyond max_rows are counted, not written).
+ * key_words = 1 (4x4: keys_out[max_rows]) or 2 (5x5: keys_out[max_rows][2] = key, reserved). */
 int q2048_table_export(const q2048_slot *table, int cap_log2, uint64_t *keys_out, float *q_out,
-                       int64_t max_rows, int64_t *count, void *stream);
+                       int64_t max_rows, int key_words, int64_t *count, void *stream);
 
 #ifdef __cplusplus
 }

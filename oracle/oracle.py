@@ -243,8 +243,8 @@ class Agent:
                                       discount_factor, exploration_rate, exploration_min, n)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_agent_free(self._h)
+        if getattr(self, "_h", None) and _lib is not None:  # _lib is gone at interpreter exit
+            _lib.orc_agent_free(self._h)
             self._h = None
 
     class _View(C.Structure):

@@ -4,7 +4,7 @@
 // against the CPU oracle, exhaustively, in the GPU-less build container.
 #include <cstring>
 
-#include "q2048_core.hpp"
+#include "q2048_core5.hpp"
 
 using namespace q2048;
 
@@ -143,6 +143,69 @@ void hc_luts(double* pow12, double* log2p1, double* stall) {
 
 void hc_log2_ge1(const double* x, int64_t n, double* out) {
   for (int64_t i = 0; i < n; ++i) out[i] = log2_ge1(x[i]);
+}
+
+// ---- 5x5 geometry (q2048_core5.hpp): boards are uint8[25] ----
+void hc5_move(const uint8_t* in, const uint8_t* actions, int64_t n, uint8_t* out, uint32_t* score,
+              uint8_t* moved) {
+  for (int64_t i = 0; i < n; ++i) {
+    Board5 b = board5_from_bytes(in + 25 * i);
+    uint32_t s;
+    moved[i] = move(b, actions[i], s);
+    score[i] = s;
+    board5_to_bytes(b, out + 25 * i);
+  }
+}
+
+void hc5_spawn(const uint8_t* in, const uint32_t* xpos, const uint32_t* xval, int64_t n, uint8_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    Board5 b = board5_from_bytes(in + 25 * i);
+    spawn(b, xpos[i], xval[i]);
+    board5_to_bytes(b, out + 25 * i);
+  }
+}
+
+void hc5_board_props(const uint8_t* in, int64_t n, uint8_t* over, uint8_t* mx, uint32_t* empties,
+                     uint64_t* keys, uint8_t* roundtrip) {
+  for (int64_t i = 0; i < n; ++i) {
+    Board5 b = board5_from_bytes(in + 25 * i);
+    over[i] = game_over(b);
+    mx[i] = (uint8_t)max_log2(b);
+    empties[i] = empty_mask(b);
+    Key5 k = pack_key(b);
+    keys[2 * i] = k.k0; keys[2 * i + 1] = k.k1;
+    board5_to_bytes(unpack_key(k), roundtrip + 25 * i);
+  }
+}
+
+void hc5_init_envs(uint8_t* boards, uint8_t* aux, int64_t n, uint64_t seed, uint64_t env_id0) {
+  for (int64_t i = 0; i < n; ++i) {
+    Board5 b; Aux a;
+    init_env(b, a, seed, env_id0 + (uint64_t)i);
+    board5_to_bytes(b, boards + 25 * i);
+    store_aux(aux + 16 * i, a);
+  }
+}
+
+void hc5_rollout_env(uint8_t* boards, uint8_t* aux, int64_t n, int64_t steps, uint64_t seed,
+                     uint64_t env_id0, uint32_t ctr0, const uint8_t* actions, float* reward,
+                     uint8_t* done) {
+  for (int64_t t = 0; t < steps; ++t)
+    for (int64_t i = 0; i < n; ++i) {
+      Board5 b = board5_from_bytes(boards + 25 * i);
+      Aux a = load_aux(aux + 16 * i);
+      const uint64_t id = env_id0 + (uint64_t)i;
+      Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
+      StepOut o = env_step(b, a, actions[t * n + i], x.x2, x.x3);
+      reward[t * n + i] = o.reward; done[t * n + i] = o.done;
+      if (o.done) begin_episode(b, a, seed, id);
+      board5_to_bytes(b, boards + 25 * i);
+      store_aux(aux + 16 * i, a);
+    }
+}
+
+void hc_kth_set_bit32(const uint32_t* mask, const uint8_t* k, int64_t n, uint8_t* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = (uint8_t)kth_set_bit32(mask[i], k[i]);
 }
 
 uint64_t hc_mix64(uint64_t x) { return mix64(x); }

@@ -318,3 +318,115 @@ def test_salt_and_mix(hc):
     seen = {hc.hc_lane_salt(i) for i in range(100000)}
     assert len(seen) == 100000 and all(s & 1 for s in list(seen)[:100])
     assert hc.hc_mix64(0) == 0 and hc.hc_mix64(1) != hc.hc_mix64(2)
+
+
+# ---------------------------------------------------------------------------------------------
+# 5x5 geometry (csrc/q2048_core5.hpp) against the oracle's n-generic restatement (n = 5).  The
+# reference hard-codes n = 4; the oracle's generic code is the one pinned to it at n = 4 above.
+# ---------------------------------------------------------------------------------------------
+def hc5_move(hc, boards, actions):
+    boards = np.ascontiguousarray(boards, dtype=np.uint8)
+    actions = np.ascontiguousarray(actions, dtype=np.uint8)
+    n = len(boards)
+    out = np.zeros_like(boards); score = np.zeros(n, np.uint32); moved = np.zeros(n, np.uint8)
+    hc.hc5_move(p(boards), p(actions), C.c_int64(n), p(out), p(score), p(moved))
+    return out, score, moved
+
+
+def test_5x5_lines_all_directions(hc, O):
+    """Random and structured 5-cell lines (log2 0..26) as row 0 / column 0, 4 directions.
+    (The move score is a uint32 on the device: exact while merged tiles stay below 2^30.)"""
+    rng = np.random.default_rng(50)
+    lines = np.concatenate([
+        np.where(rng.random((60000, 5)) < 0.75, rng.integers(1, 5, size=(60000, 5)), 0),  # many merges
+        np.where(rng.random((20000, 5)) < 0.6, rng.integers(1, 27, size=(20000, 5)), 0),
+        np.array([[1, 1, 1, 1, 1], [2, 2, 2, 2, 0], [0, 0, 0, 0, 3], [1, 1, 2, 2, 3], [26, 26, 0, 26, 26],
+                  [1, 0, 1, 0, 1], [5, 5, 5, 0, 5], [0, 0, 0, 0, 0], [1, 2, 3, 4, 5]]),
+    ]).astype(np.uint8)
+    want_line, want_score, want_moved = [], [], []
+    for ln in lines:
+        o, s, m = O.move_left_line(ln)
+        want_line.append(o); want_score.append(s); want_moved.append(m)
+    want_line = np.array(want_line); want_score = np.array(want_score); want_moved = np.array(want_moved)
+    n = len(lines)
+    for action in range(4):
+        boards = np.zeros((n, 5, 5), np.uint8); want = np.zeros_like(boards)
+        if action == 0:
+            boards[:, 0, :], want[:, 0, :] = lines, want_line
+        elif action == 2:
+            boards[:, 0, ::-1], want[:, 0, ::-1] = lines, want_line
+        elif action == 1:
+            boards[:, :, 0], want[:, :, 0] = lines, want_line
+        else:
+            boards[:, ::-1, 0], want[:, ::-1, 0] = lines, want_line
+        out, s, m = hc5_move(hc, boards.reshape(n, 25), np.full(n, action))
+        assert np.array_equal(out, want.reshape(n, 25)), action
+        assert np.array_equal(s.astype(np.int64), want_score), action
+        assert np.array_equal(m.astype(bool), want_moved), action
+
+
+def test_5x5_moves_spawn_props_match_oracle(hc, O):
+    rng = np.random.default_rng(51)
+    n = 20000
+    boards = np.where(rng.random((n, 25)) < rng.random((n, 1)), rng.integers(1, 8, size=(n, 25)), 0).astype(np.uint8)
+    boards[:3000] = rng.integers(1, 13, size=(3000, 25))         # full boards: ~3 % are dead
+    boards[3000:3100] = [(1 + (r + c) % 2) for r in range(5) for c in range(5)]   # dead checkerboard
+    actions = rng.integers(0, 4, size=n).astype(np.uint8)
+    out, s, m = hc5_move(hc, boards, actions)
+    xp = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    xv = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    sp = np.zeros_like(out)
+    hc.hc5_spawn(p(out), p(xp), p(xv), C.c_int64(n), p(sp))
+    over = np.zeros(n, np.uint8); mx = np.zeros(n, np.uint8); em = np.zeros(n, np.uint32)
+    keys = np.zeros((n, 2), np.uint64); rt = np.zeros_like(boards)
+    hc.hc5_board_props(p(boards), C.c_int64(n), p(over), p(mx), p(em), p(keys), p(rt))
+    for i in range(n):
+        b, sc, mv = O.move(boards[i], int(actions[i]), n=5)
+        assert out[i].tolist() == b.tolist() and s[i] == sc and bool(m[i]) == mv, i
+        assert sp[i].tolist() == O.add_number(out[i], int(xp[i]), int(xv[i]), n=5).tolist(), i
+        if i < 6000:
+            assert bool(over[i]) == O.is_game_over(boards[i], n=5), i
+    assert over[3000:3100].all() and 0 < over[:3000].sum() < 3000
+    assert np.array_equal(mx, boards.max(axis=1))
+    assert np.array_equal(em, ((boards == 0) * (1 << np.arange(25))).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(rt, boards)                                   # key pack/unpack round trip
+    assert len({(int(a), int(b)) for a, b in keys}) == len({bytes(b) for b in boards})
+    assert np.all(keys >> np.uint64(63) == 1)
+
+
+def test_kth_set_bit32(hc):
+    rng = np.random.default_rng(52)
+    masks = rng.integers(1, 1 << 25, size=200000, dtype=np.uint32)
+    masks[:25] = 1 << np.arange(25)
+    masks[25] = (1 << 25) - 1
+    pc = np.array([bin(int(m)).count("1") for m in masks])
+    ks = (rng.random(len(masks)) * pc).astype(np.uint8)
+    out = np.zeros(len(masks), np.uint8)
+    hc.hc_kth_set_bit32(p(masks), p(ks), C.c_int64(len(masks)), p(out))
+    for m, k, o in zip(masks[:5000].tolist(), ks[:5000].tolist(), out[:5000].tolist()):
+        assert [i for i in range(25) if m >> i & 1][k] == o
+    below = (masks.astype(np.int64) & ((1 << out.astype(np.int64)) - 1))
+    assert np.array_equal(np.array([bin(int(x)).count("1") for x in below]), ks)
+    assert np.all((masks >> out) & 1)
+
+
+def test_5x5_rollout_env_only_matches_oracle(hc, O):
+    B, steps, seed, id0, ctr0 = 64, 1500, 99, 12345, 5
+    rng = np.random.default_rng(53)
+    actions = np.where(rng.random((steps, B)) < 0.6, rng.integers(0, 2, size=(steps, B)),
+                       rng.integers(0, 4, size=(steps, B))).astype(np.uint8)
+    actions[:, :4] = 1
+    envs = O.envs_init(B, 5, seed, id0)
+    boards = np.zeros((B, 25), np.uint8); aux = np.zeros(B, dtype=AUX_DTYPE)
+    hc.hc5_init_envs(p(boards), p(aux), C.c_int64(B), C.c_uint64(seed), C.c_uint64(id0))
+    assert np.array_equal(boards, envs["board"][:, :25])
+    si, sf, acts, rew, dn = O.rollout(envs, None, steps, seed, id0, ctr0, actions=actions, record=True)
+    r32 = np.zeros((steps, B), np.float32); done = np.zeros((steps, B), np.uint8)
+    hc.hc5_rollout_env(p(boards), p(aux), C.c_int64(B), C.c_int64(steps), C.c_uint64(seed),
+                       C.c_uint64(id0), ctr0, p(actions), p(r32), p(done))
+    assert np.array_equal(boards, envs["board"][:, :25])
+    assert np.array_equal(done, dn) and dn.sum() > 20
+    assert np.array_equal(r32, rew.astype(np.float32))
+    assert np.array_equal(aux["score"], envs["score"])
+    assert np.array_equal(aux["episode"], envs["episode"])
+    assert np.array_equal(aux["prev_max"], envs["previous_max_log2"])

@@ -205,11 +205,11 @@ def test_abi_argument_errors(pkg):
     assert L.q2048_env_init(None, a.data_ptr(), 4, 4, 0, 0, None) == -1
     assert L.q2048_env_init(b.data_ptr(), a.data_ptr(), -1, 4, 0, 0, None) == -2
     assert L.q2048_env_init(b.data_ptr() + 1, a.data_ptr(), 4, 4, 0, 0, None) == -3
-    assert L.q2048_env_init(b.data_ptr(), a.data_ptr(), 4, 5, 0, 0, None) == -4
+    assert L.q2048_env_init(b.data_ptr(), a.data_ptr(), 4, 6, 0, 0, None) == -4
     assert L.q2048_env_init(b.data_ptr(), a.data_ptr(), 0, 4, 0, 0, None) == 0   # empty batch
     assert b"NULL" in L.q2048_strerror(-1)
     with pytest.raises(NotImplementedError):
-        pkg.BatchedGame2048Env(4, board_size=5, device=DEV)
+        pkg.BatchedGame2048Env(4, board_size=6, device=DEV)
     with pytest.raises(RuntimeError):
         pkg.BatchedGame2048Env(4, device="cpu")
 
@@ -524,3 +524,102 @@ def test_reference_surface_adapters(pkg):
         assert q_values.shape == (4,) and info == np.max(env.game.board)
         agent.decay_exploration(episode)
     assert agent.epsilon == 0.01 and len(agent.q_table) > 10
+
+
+# ---------------------------------------------------------------------------------------------
+# 5x5 boards (BASELINE configs[4]).  The reference hard-codes 4x4; the oracle's n-generic
+# restatement (pinned to the reference at n = 4) is the checker at n = 5.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 255, 256, 1000])
+def test_5x5_env_init_and_rollout_match_oracle(pkg, O, B):
+    """25-byte boards staged through LDS (ragged last block), step / reset(done) vs the oracle."""
+    steps, seed, id0 = 300, 61, 4_000_000_000
+    rng = np.random.default_rng(B)
+    actions = np.where(rng.random((steps, B)) < 0.6, rng.integers(0, 2, size=(steps, B)),
+                       rng.integers(0, 4, size=(steps, B))).astype(np.uint8)
+    actions[:, : max(1, B // 50)] = 2
+    envs = O.envs_init(B, 5, seed, id0)
+    env = pkg.BatchedGame2048Env(B, board_size=5, seed=seed, env_id0=id0, device=DEV)
+    assert env.boards.shape == (B, 25)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :25])
+    si, sf, _, rew, dn = O.rollout(envs, None, steps, seed, id0, 0, actions=actions, record=True)
+    acts = torch.from_numpy(actions).to(DEV)
+    drew, ddn = [], []
+    for t in range(steps):
+        _, r, d, mt = env.step(acts[t])
+        drew.append(r.clone()); ddn.append(d.clone())
+        env.reset(d)
+    ddn = torch.stack(ddn).cpu().numpy().astype(np.uint8)
+    assert np.array_equal(ddn, dn)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :25])
+    assert_rewards(torch.stack(drew).cpu().numpy(), rew, "5x5 rollout")
+    assert_aux(env.aux_fields(), envs, "5x5 rollout")
+    assert env.check_status() == 0
+
+
+def test_5x5_fused_rollout_matches_oracle_independent_lanes(pkg, O):
+    B, steps, seed, id0, eps, lr, gamma = 150, 400, 23, 987654, 0.2, 0.1, 0.99
+    envs = O.envs_init(B, 5, seed, id0)
+    agents = [O.Agent(100, 4, lr, gamma, eps, n=5) for _ in range(B)]
+    tot_i = np.zeros(O.ST_NI, np.int64)
+    for i in range(B):
+        si, sf = O.rollout(envs[i:i + 1], agents[i], steps, seed, id0 + i, 0)
+        tot_i += si
+    env = pkg.BatchedGame2048Env(B, board_size=5, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma,
+                                      exploration_rate=eps, capacity_log2=18, seed=seed, env_id0=id0,
+                                      device=DEV, independent=True, board_size=5)
+    for k in (1, 99, 300):                       # split launches: state carried in HBM in between
+        agent.fused_rollout(env, k)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :25])
+    assert_aux(env.aux_fields(), envs, "5x5 fused")
+    worst = 0.0
+    for i, oa in enumerate(agents):
+        keys, vals = oa.dump()
+        got = agent.q_values(t8(keys), env_id=id0 + i).cpu().numpy()
+        assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), i
+        worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
+    print(f"[q] 5x5 fused: worst relative Q error {worst:.2e}")
+    st = agent.stats()
+    assert st["steps"] == B * steps and st["episodes"] == tot_i[O.ST_EPISODES]
+    assert st["valid_moves"] == tot_i[O.ST_VALID] and st["score_sum"] == tot_i[O.ST_SCORE]
+    assert st["inserts"] == agent.table_size() == sum(len(oa) for oa in agents)
+    assert st["drops"] == 0 and agent.check_status() == 0
+
+
+def test_5x5_fused_equals_unfused(pkg):
+    B, steps, seed, id0 = 200, 80, 5, 31
+
+    def mk():
+        e = pkg.BatchedGame2048Env(B, board_size=5, seed=seed, env_id0=id0, device=DEV)
+        a = pkg.BatchedQLearningAgent(100, exploration_rate=0.3, capacity_log2=17, seed=seed,
+                                      env_id0=id0, device=DEV, independent=True, board_size=5)
+        return e, a
+
+    e1, a1 = mk(); a1.fused_rollout(e1, steps)
+    e2, a2 = mk(); _unfused_loop(pkg, e2, a2, steps)
+    assert torch.equal(e1.boards, e2.boards)
+    k1, q1 = a1.export_rows(); k2, q2 = a2.export_rows()
+    o1 = np.lexsort((k1[:, 1], k1[:, 0])); o2 = np.lexsort((k2[:, 1], k2[:, 0]))
+    assert np.array_equal(k1[o1], k2[o2]) and np.array_equal(q1[o1], q2[o2])
+
+
+def test_5x5_shared_table_pure_exploration(pkg, O):
+    """eps = 1 on a shared table: trajectories and the table's key set equal the oracle's."""
+    B, steps, seed, id0 = 5000, 120, 77, 1
+    env = pkg.BatchedGame2048Env(B, board_size=5, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2=21, seed=seed,
+                                      env_id0=id0, device=DEV, board_size=5)
+    agent.fused_rollout(env, steps)
+    envs = O.envs_init(B, 5, seed, id0)
+    oa = O.Agent(100, 4, 0.1, 0.9, 1.0, n=5)
+    si, sf = O.rollout(envs, oa, steps, seed, id0, 0)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :25])
+    st = agent.stats()
+    assert st["inserts"] == agent.table_size() == len(oa)
+    assert st["valid_moves"] == si[O.ST_VALID] and st["episodes"] == si[O.ST_EPISODES]
+    d = agent.export_dict()
+    keys, vals = oa.dump()
+    want = {tuple(tuple(int(v) for v in r) for r in pkg.boards_to_raw(k)) for k in keys}
+    assert set(d.keys()) == want
+    assert agent.check_status() == 0

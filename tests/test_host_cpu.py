@@ -30,7 +30,8 @@ def test_abi_exports_every_declared_symbol(pkg):
     assert L.q2048_strerror(-4).decode().startswith("unsupported")
     # host-side argument validation needs no device
     assert L.q2048_env_init(None, None, 4, 4, 0, 0, None) == -1
-    assert L.q2048_env_init(None, None, 4, 5, 0, 0, None) == -4
+    assert L.q2048_env_init(None, None, 4, 6, 0, 0, None) == -4
+    assert L.q2048_env_init(None, None, 4, 5, 0, 0, None) == -1            # 5x5 is supported
     assert L.q2048_fused_rollout(None, None, None, 20, 4, 4, 1, 0.5, 0.1, 0.9, 0, 0, 0, 0, None,
                                  None, None, None) == -1
     assert L.q2048_q_choose(16, 99, 16, 4, 4, 0.5, 0, 0, 0, 0, 16, 16, None) == -2  # bad cap_log2
