@@ -236,6 +236,54 @@ class BatchedQLearningAgent:
             raise ValueError("an action outside 0..3 was passed to update_q_value()")
         return s
 
+    # -- checkpoint / resume (the reference never saves its q_table) ------
+    def state_dict(self, compact: bool = True) -> dict:
+        """Host copy of the learner: the occupied rows (compact) or the raw table, the epsilon
+        schedule, counters and statistics.  `load_state_dict` on an agent built with the same
+        constructor arguments continues the run; compact rows are re-inserted, so slot positions
+        may differ but every lookup returns the same values."""
+        sd = {"capacity_log2": self.capacity_log2, "board_size": self.board_size,
+              "flags": self.flags, "ctr": self.ctr, "seed": self.seed, "env_id0": self.env_id0,
+              "lr": self.lr, "gamma": self.gamma, "schedule": dict(vars(self.schedule)),
+              "stats_i": self.stats_i.cpu(), "stats_f": self.stats_f.cpu()}
+        if compact:
+            sd["keys"], sd["q"] = self.export_rows()
+        else:
+            sd["table"] = self.table.cpu()
+        return sd
+
+    def load_state_dict(self, sd: dict) -> None:
+        if sd["board_size"] != self.board_size:
+            raise ValueError("checkpoint was taken with another board size")
+        self.ctr, self.seed, self.env_id0 = int(sd["ctr"]), int(sd["seed"]), int(sd["env_id0"])
+        self.lr, self.gamma, self.flags = sd["lr"], sd["gamma"], int(sd["flags"])
+        vars(self.schedule).update(sd["schedule"])
+        self.stats_i.copy_(sd["stats_i"])
+        self.stats_f.copy_(sd["stats_f"])
+        self.table.zero_()
+        if "table" in sd:
+            if sd["capacity_log2"] != self.capacity_log2:
+                raise ValueError("raw tables only load into the same capacity")
+            self.table.copy_(sd["table"])
+        else:
+            self.import_rows(sd["keys"], sd["q"])
+
+    def import_rows(self, keys: np.ndarray, q: np.ndarray) -> None:
+        """Inserts (key, q[4]) rows exported by `export_rows` (any capacity that holds them)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(len(q), -1)
+        rows = len(q)
+        if rows == 0:
+            return
+        if rows * 2 > (1 << self.capacity_log2):
+            raise ValueError("table too small for the checkpoint (load factor would exceed 0.5)")
+        tk = torch.from_numpy(keys.view(np.int64)).to(self.device)
+        tq = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.device)
+        N.check(N.lib().q2048_table_import(_ptr(self.table), self.capacity_log2, _ptr(tk), _ptr(tq),
+                                           rows, keys.shape[1], _ptr(self.status),
+                                           _stream(self.device)), "table_import")
+        if int(self.status.item()) & N.STATUS_TABLE_FULL:
+            raise RuntimeError("table_import dropped rows (probe limit)")
+
     # -- argument plumbing -----------------------------------------------------------------
     def _boards(self, b) -> torch.Tensor:
         if not isinstance(b, torch.Tensor):

@@ -595,6 +595,21 @@ __global__ __launch_bounds__(kBlock) void k_table_export(const q2048_slot* table
   }
 }
 
+template <int WORDS>
+__global__ __launch_bounds__(kBlock) void k_table_import(q2048_slot* table, u64 mask, const u64* keys,
+                                                         const float* q, int64_t rows, uint32_t* status) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= rows) return;
+  typename Geo<WORDS == 1 ? 4 : 5>::Key key;
+  key.k0 = keys[i * WORDS];
+  if constexpr (WORDS == 2) key.k1 = keys[i * 2 + 1];
+  bool inserted;
+  const int64_t slot = probe_insert(table, mask, key, key_home(key, mask), inserted);
+  if (slot < 0) { atomicOr(status, Q2048_STATUS_TABLE_FULL); return; }
+  const float4 v = reinterpret_cast<const float4*>(q)[i];
+  table[slot].q[0] = v.x; table[slot].q[1] = v.y; table[slot].q[2] = v.z; table[slot].q[3] = v.w;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side of the ABI
 // ---------------------------------------------------------------------------------------------
@@ -764,6 +779,23 @@ int q2048_fused_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int 
   if (B == 0 || steps == 0) return Q2048_OK;
   Q2048_LAUNCH(k_fused_rollout, n, B, stream, boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B,
                (int)steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status);
+  return launch_status();
+}
+
+int q2048_table_import(q2048_slot* table, int cap_log2, const uint64_t* keys, const float* q,
+                       int64_t rows, int key_words, uint32_t* status, void* stream) {
+  if (int e = check_table(table, cap_log2)) return e;
+  if (!keys || !q || !status) return Q2048_ERR_NULL;
+  if (rows < 0 || (key_words != 1 && key_words != 2)) return Q2048_ERR_SIZE;
+  if (!aligned16(q)) return Q2048_ERR_ALIGN;
+  if (rows == 0) return Q2048_OK;
+  const u64 mask = (1ull << cap_log2) - 1ull;
+  if (key_words == 1)
+    hipLaunchKernelGGL(k_table_import<1>, dim3(grid_for(rows)), dim3(kBlock), 0, (hipStream_t)stream,
+                       table, mask, reinterpret_cast<const u64*>(keys), q, rows, status);
+  else
+    hipLaunchKernelGGL(k_table_import<2>, dim3(grid_for(rows)), dim3(kBlock), 0, (hipStream_t)stream,
+                       table, mask, reinterpret_cast<const u64*>(keys), q, rows, status);
   return launch_status();
 }
 

@@ -104,6 +104,19 @@ class BatchedGame2048Env:
     def max_log2(self) -> torch.Tensor:
         return self._max
 
+    # -- checkpoint ---------------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """Everything needed to continue this batch bit-exactly (host tensors)."""
+        return {"boards": self.boards.cpu(), "aux": self.aux.cpu(), "ctr": self.ctr,
+                "seed": self.seed, "env_id0": self.env_id0, "board_size": self.board_size}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if (sd["board_size"], tuple(sd["boards"].shape)) != (self.board_size, tuple(self.boards.shape)):
+            raise ValueError("checkpoint was taken with another batch or board size")
+        self.boards.copy_(sd["boards"])
+        self.aux.copy_(sd["aux"])
+        self.ctr, self.seed, self.env_id0 = int(sd["ctr"]), int(sd["seed"]), int(sd["env_id0"])
+
     # -- helpers --------------------------------------------------------------------------
     def aux_fields(self) -> dict:
         """Host copy of the aux records as numpy fields (tests / logging)."""

@@ -184,6 +184,12 @@ int q2048_table_count(const q2048_slot *table, int cap_log2, int64_t *count, voi
 int q2048_table_export(const q2048_slot *table, int cap_log2, uint64_t *keys_out, float *q_out,
                        int64_t max_rows, int key_words, int64_t *count, void *stream);
 
+/* Inverse of q2048_table_export (resume / load a table trained elsewhere): inserts `rows`
+ * (key, q[4]) pairs into the table, key_words as above.  A key already present has its row
+ * overwritten; a row that finds no slot within the probe limit sets Q2048_STATUS_TABLE_FULL. */
+int q2048_table_import(q2048_slot *table, int cap_log2, const uint64_t *keys, const float *q,
+                       int64_t rows, int key_words, uint32_t *status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -623,3 +623,111 @@ def test_5x5_shared_table_pure_exploration(pkg, O):
     want = {tuple(tuple(int(v) for v in r) for r in pkg.boards_to_raw(k)) for k in keys}
     assert set(d.keys()) == want
     assert agent.check_status() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# full size, table limits, checkpoint
+# ---------------------------------------------------------------------------------------------
+def test_full_size_1m_boards_properties(pkg, O):
+    """BASELINE configs[2] size (1,048,576 boards, shared hash table).  eps = 1 makes every board
+    trajectory a pure function of (seed, global env id, step), so sampled lanes are checked
+    bit-exactly against the oracle and the whole batch through size-independent invariants."""
+    B, seed, id0, launches, S = 1 << 20, 2024, 7, 3, 16
+    env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(1000, exploration_rate=1.0, discount_factor=0.99,
+                                      capacity_log2=27, seed=seed, env_id0=id0, device=DEV)
+    for _ in range(launches):
+        agent.fused_rollout(env, S)
+    steps = launches * S
+    boards = env.boards.cpu().numpy()
+    aux = env.aux_fields()
+    rng = np.random.default_rng(0)
+    sample = np.unique(np.concatenate([[0, 1, 63, 64, 255, 256, B - 257, B - 2, B - 1],
+                                       rng.integers(0, B, size=1500)]))
+    for i in sample.tolist():
+        envs = O.envs_init(1, 4, seed, id0 + i)
+        O.rollout(envs, O.Agent(10, 4, 0.1, 0.99, 1.0), steps, seed, id0 + i, 0)
+        assert boards[i].tolist() == envs["board"][0, :16].tolist(), i
+        assert aux["score"][i] == envs["score"][0] and aux["episode"][i] == envs["episode"][0], i
+        assert aux["cons_count"][i] == envs["consecutive_count"][0], i
+    st = agent.stats()
+    assert st["steps"] == B * steps and st["explored"] == B * steps
+    assert st["episodes"] == int(aux["episode"].astype(np.int64).sum())      # every reset is counted
+    assert st["inserts"] == agent.table_size() and st["drops"] == 0
+    assert agent.check_status() == 0 and env.check_status() == 0
+    assert boards.max() <= 15 and (boards > 0).sum(axis=1).min() >= 2        # legal boards only
+    assert sum(st["max_tile_hist"].values()) == st["episodes"]
+    # determinism: a second run of the same job gives the same boards and statistics
+    env2 = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+    agent2 = pkg.BatchedQLearningAgent(1000, exploration_rate=1.0, discount_factor=0.99,
+                                       capacity_log2=27, seed=seed, env_id0=id0, device=DEV)
+    agent2.fused_rollout(env2, steps)            # one launch instead of three
+    assert torch.equal(env.boards, env2.boards) and torch.equal(env.aux, env2.aux)
+    st2 = agent2.stats()
+    for k in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "max_tile_hist"):
+        assert st[k] == st2[k], k
+
+
+def test_table_full_drops_are_counted_not_raised(pkg, O):
+    """A table that is too small: updates are dropped and counted, the status word says so,
+    nothing raises, and the env trajectories are untouched."""
+    B, steps, seed = 4096, 30, 5
+    env = pkg.BatchedGame2048Env(B, seed=seed, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2=10, seed=seed, device=DEV)
+    agent.fused_rollout(env, steps)
+    st = agent.stats()
+    assert st["drops"] > 0 and st["inserts"] <= 1 << 10 and st["inserts"] == agent.table_size()
+    assert agent.check_status() & pkg._native.STATUS_TABLE_FULL
+    envs = O.envs_init(B, 4, seed, 0)
+    O.rollout(envs, O.Agent(100, 4, 0.1, 0.9, 1.0), steps, seed, 0, 0)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16])
+
+
+@pytest.mark.parametrize("n", [4, 5])
+def test_checkpoint_resume_is_bit_exact(pkg, n):
+    """state_dict / load_state_dict: stop after 60 steps, reload into fresh
+    objects with a DIFFERENT table capacity, continue 40 steps == the uninterrupted run."""
+    B, seed, id0 = 300, 9, 4242
+
+    def mk(cap):
+        e = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+        a = pkg.BatchedQLearningAgent(100, exploration_rate=0.3, discount_factor=0.95, capacity_log2=cap,
+                                      seed=seed, env_id0=id0, device=DEV, independent=True, board_size=n)
+        return e, a
+
+    e1, a1 = mk(17); a1.fused_rollout(e1, 60)
+    sd_env, sd_agent = e1.state_dict(), a1.state_dict()
+    a1.decay_exploration(0); eps_after = a1.epsilon
+    a1.fused_rollout(e1, 40)
+    e2, a2 = mk(19)
+    e2.load_state_dict(sd_env); a2.load_state_dict(sd_agent)
+    assert a2.table_size() == len(sd_agent["q"]) and (e2.ctr, a2.ctr) == (60, 60)
+    a2.decay_exploration(0); assert a2.epsilon == eps_after
+    a2.fused_rollout(e2, 40)
+    assert torch.equal(e1.boards, e2.boards) and torch.equal(e1.aux, e2.aux)
+    k1, q1 = a1.export_rows(); k2, q2 = a2.export_rows()
+    k1 = k1.reshape(len(q1), -1); k2 = k2.reshape(len(q2), -1)
+    o1 = np.lexsort(k1.T[::-1]); o2 = np.lexsort(k2.T[::-1])
+    assert np.array_equal(k1[o1], k2[o2]) and np.array_equal(q1[o1], q2[o2])
+    s1, s2 = a1.stats(), a2.stats()
+    for k in ("steps", "episodes", "valid_moves", "score_sum", "explored"):
+        assert s1[k] == s2[k], k
+
+
+def test_export_dict_is_the_reference_table(pkg, O):
+    """A GPU-trained table in the reference's own form {tuple-of-tuples: float64[4]}."""
+    steps, seed, id0 = 800, 12, 99
+    env = pkg.BatchedGame2048Env(1, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=0.2, discount_factor=0.99,
+                                      capacity_log2=14, seed=seed, env_id0=id0, device=DEV)
+    agent.fused_rollout(env, steps)
+    envs = O.envs_init(1, 4, seed, id0)
+    oa = O.Agent(100, 4, 0.1, 0.99, 0.2)
+    O.rollout(envs, oa, steps, seed, id0, 0)
+    d = agent.export_dict()
+    keys, vals = oa.dump()
+    assert len(d) == len(keys)
+    for k, v in zip(keys, vals):
+        state = tuple(tuple(int(x) for x in r) for r in pkg.boards_to_raw(k))
+        assert state in d and d[state].dtype == np.float64
+        assert np.allclose(d[state], v, rtol=1e-5, atol=1e-6)
