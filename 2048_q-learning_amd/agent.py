@@ -304,6 +304,98 @@ class BatchedQLearningAgent:
         return v
 
 
+class BatchedRowTupleAgent:
+    """BASELINE configs[1]: "flat-array Q over row-tuple features".  The reference's method names
+    (choose_action / update_q_value / decay_exploration / epsilon) over a different table: a
+    linear Q over the four 16-bit row indices, Q(s,a) = sum_r W[r][idx_r(s)][a], W float32
+    [4, 65536, 4] (4 MiB).  It is NOT the reference's whole-board dict learner; it is
+    validated against its own restatement in the oracle."""
+
+    def __init__(self, total_epochs, action_space=4, learning_rate=0.1, discount_factor=0.9,
+                 exploration_rate=1.0, exploration_min=0.01, device="cuda", seed: int = 0,
+                 env_id0: int = 0):
+        self.device = _require_gpu(device)
+        if action_space != 4:
+            raise ValueError("the 2048 action space has 4 actions")
+        self.lr, self.gamma = learning_rate, discount_factor
+        self.schedule = EpsilonSchedule(total_epochs, exploration_rate, exploration_min)
+        self.seed, self.env_id0, self.ctr, self.board_size = int(seed), int(env_id0), 0, 4
+        self.weights = torch.zeros((4, 65536, 4), dtype=torch.float32, device=self.device)
+        self.stats_i = torch.zeros(N.NSTAT_I, dtype=torch.int64, device=self.device)
+        self.stats_f = torch.zeros(N.NSTAT_F, dtype=torch.float64, device=self.device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    epsilon = property(lambda self: self.schedule.epsilon,
+                       lambda self, v: setattr(self.schedule, "epsilon", float(v)))
+
+    def decay_exploration(self, current_epoch) -> None:
+        self.schedule.decay_exploration(current_epoch)
+
+    def _boards(self, b) -> torch.Tensor:
+        if not isinstance(b, torch.Tensor):
+            b = torch.as_tensor(np.asarray(b, dtype=np.uint8))
+        b = b.to(self.device)
+        if b.dtype != torch.uint8 or b.dim() != 2 or b.shape[1] != 16:
+            raise ValueError("boards must be uint8 with shape (B, 16)")
+        return b.contiguous()
+
+    def choose_action(self, boards) -> torch.Tensor:
+        boards = self._boards(boards)
+        B = boards.shape[0]
+        actions = torch.empty(B, dtype=torch.uint8, device=self.device)
+        N.check(N.lib().q2048_rt_choose(_ptr(self.weights), _ptr(boards), B, float(self.epsilon),
+                                        self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, _ptr(actions),
+                                        _stream(self.device)), "rt_choose")
+        self.ctr += 1
+        return actions
+
+    def update_q_value(self, boards, actions, reward, next_boards, done) -> None:
+        boards, next_boards = self._boards(boards), self._boards(next_boards)
+        B = boards.shape[0]
+        vec = lambda v, dt: torch.as_tensor(v).to(device=self.device, dtype=dt).contiguous()  # noqa: E731
+        actions, reward, done = vec(actions, torch.uint8), vec(reward, torch.float32), vec(done, torch.uint8)
+        if not (actions.shape == reward.shape == done.shape == (B,)):
+            raise ValueError("actions / reward / done must have shape (B,)")
+        N.check(N.lib().q2048_rt_update(_ptr(self.weights), _ptr(boards), _ptr(actions), _ptr(reward),
+                                        _ptr(next_boards), _ptr(done), B, float(self.lr),
+                                        float(self.gamma), _ptr(self.status), _stream(self.device)),
+                "rt_update")
+
+    def q_values(self, boards) -> torch.Tensor:
+        boards = self._boards(boards)
+        q = torch.empty((boards.shape[0], 4), dtype=torch.float32, device=self.device)
+        N.check(N.lib().q2048_rt_lookup(_ptr(self.weights), _ptr(boards), boards.shape[0], _ptr(q),
+                                        _stream(self.device)), "rt_lookup")
+        return q
+
+    def fused_rollout(self, env: BatchedGame2048Env, steps: int) -> None:
+        if env.board_size != 4 or env.device != self.device:
+            raise ValueError("the row-tuple learner needs a 4x4 env on the same device")
+        if (env.seed, env.env_id0, env.ctr) != (self.seed, self.env_id0, self.ctr):
+            raise ValueError("env and agent must share seed, env_id0 and step counter")
+        N.check(N.lib().q2048_rt_fused_rollout(
+            _ptr(env.boards), _ptr(env.aux), _ptr(self.weights), env.num_envs, int(steps),
+            float(self.epsilon), float(self.lr), float(self.gamma), self.seed, self.env_id0,
+            self.ctr & 0xFFFFFFFF, _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status),
+            _stream(self.device)), "rt_fused_rollout")
+        env.ctr += int(steps)
+        self.ctr += int(steps)
+
+    def stats(self, reset: bool = False) -> dict:
+        si, sf = self.stats_i.cpu().numpy(), self.stats_f.cpu().numpy()
+        if reset:
+            self.stats_i.zero_()
+            self.stats_f.zero_()
+        return stats_dict(si, sf)
+
+    def check_status(self) -> int:
+        s = int(self.status.item())
+        if s & N.STATUS_BAD_ACTION:
+            self.status.zero_()
+            raise ValueError("an action outside 0..3 was passed to update_q_value()")
+        return s
+
+
 def stats_dict(si, sf) -> dict:
     si = np.asarray(si, dtype=np.int64)
     sf = np.asarray(sf, dtype=np.float64)

@@ -426,4 +426,17 @@ Q_HD float td_value(float q_sa, float reward, float max_q_next, bool done, doubl
   return (float)((double)q_sa + lr * (target - (double)q_sa));                                // :43
 }
 
+// ------------------------------------------------------------------------------------------
+// row-tuple linear Q (BASELINE configs[1]: "flat-array Q over row-tuple features").  NOT the
+// reference's learner (its Q is keyed by the whole board, Agent/main.py:82): Q(s,a) is the sum
+// over the four rows r of W[r][idx_r(s)][a] with idx_r = pack_row(row r); same epsilon-greedy
+// and TD target as Agent/main.py:34-43, the error spread evenly over the four weights.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kRtIdx = 65536u;  // entries per row table; W is float[4][65536][4]
+Q_HD float rt_sum(float e0, float e1, float e2, float e3) { return (e0 + e1) + (e2 + e3); }
+Q_HD float rt_delta(float q_sa, float reward, float max_next, bool done, double lr, double gamma) {
+  const double target = (double)reward + (gamma * (double)max_next * (done ? 0.0 : 1.0));
+  return (float)((lr * 0.25) * (target - (double)q_sa));
+}
+
 }  // namespace q2048

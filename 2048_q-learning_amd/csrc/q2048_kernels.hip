@@ -576,6 +576,125 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
 }
 
 // ---------------------------------------------------------------------------------------------
+// row-tuple linear Q (BASELINE configs[1]), 4x4 only.  W = float[4][65536][4] (4 MiB: lives in
+// L2 / Infinity Cache).  Reads are agent-scope loads of whole 16-byte entries.  A write stores
+// old + d with the value the lane gathered (last writer wins): hot row entries are shared by
+// most of the batch, and summing every lane's delta (atomic add) multiplies the step size by the
+// number of concurrent lanes and diverges.  With one lane this is the sequential learner.
+// ---------------------------------------------------------------------------------------------
+struct RtRows { Row e0, e1, e2, e3; };
+__device__ __forceinline__ Row rt_entry(const float* w, uint32_t r, uint32_t idx) {
+  const float* e = w + (((size_t)r * kRtIdx + idx) << 2);
+  const u64 a = ld_u64(e), b = ld_u64(e + 2);
+  return Row{bits_f32((uint32_t)a), bits_f32((uint32_t)(a >> 32)), bits_f32((uint32_t)b),
+             bits_f32((uint32_t)(b >> 32))};
+}
+__device__ __forceinline__ RtRows rt_gather(const float* w, const Board& b) {
+  return RtRows{rt_entry(w, 0, pack_row(b.r0)), rt_entry(w, 1, pack_row(b.r1)),
+                rt_entry(w, 2, pack_row(b.r2)), rt_entry(w, 3, pack_row(b.r3))};
+}
+__device__ __forceinline__ Row rt_q(const RtRows& e) {
+  return Row{rt_sum(e.e0.q0, e.e1.q0, e.e2.q0, e.e3.q0), rt_sum(e.e0.q1, e.e1.q1, e.e2.q1, e.e3.q1),
+             rt_sum(e.e0.q2, e.e1.q2, e.e2.q2, e.e3.q2), rt_sum(e.e0.q3, e.e1.q3, e.e2.q3, e.e3.q3)};
+}
+__device__ __forceinline__ void rt_scatter(float* w, const Board& b, const RtRows& e, int act, float d) {
+  float* base = w + act;
+  base[((size_t)0 * kRtIdx + pack_row(b.r0)) << 2] = row_get(e.e0, act) + d;
+  base[((size_t)1 * kRtIdx + pack_row(b.r1)) << 2] = row_get(e.e1, act) + d;
+  base[((size_t)2 * kRtIdx + pack_row(b.r2)) << 2] = row_get(e.e2, act) + d;
+  base[((size_t)3 * kRtIdx + pack_row(b.r3)) << 2] = row_get(e.e3, act) + d;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rt_choose(const float* w, const uint8_t* boards, int64_t B,
+                                                      double eps, uint64_t seed, uint64_t env_id0,
+                                                      uint32_t ctr, uint8_t* actions) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  Stage<4> st;
+  const Board b = load_board(boards, i, B, st);
+  const Draws x = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamStep);
+  int act;
+  if (draw_uniform(x.x0) < eps) act = draw_action(x.x1);
+  else { const Row q = rt_q(rt_gather(w, b)); act = argmax4(q.q0, q.q1, q.q2, q.q3); }
+  actions[i] = (uint8_t)act;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rt_lookup(const float* w, const uint8_t* boards, int64_t B,
+                                                      float* q_out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  Stage<4> st;
+  const Row q = rt_q(rt_gather(w, load_board(boards, i, B, st)));
+  reinterpret_cast<float4*>(q_out)[i] = make_float4(q.q0, q.q1, q.q2, q.q3);
+}
+
+__global__ __launch_bounds__(kBlock) void k_rt_update(float* w, const uint8_t* s, const uint8_t* actions,
+                                                      const float* reward, const uint8_t* s2,
+                                                      const uint8_t* done, int64_t B, double lr,
+                                                      double gamma, uint32_t* status) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  Stage<4> st;
+  const int act = actions[i];
+  if (act > 3) { atomicOr(status, Q2048_STATUS_BAD_ACTION); return; }
+  const Board b_s = load_board(s, i, B, st), b_n = load_board(s2, i, B, st);
+  const Row qn = rt_q(rt_gather(w, b_n));
+  const RtRows es = rt_gather(w, b_s);
+  const float d = rt_delta(row_get(rt_q(es), act), reward[i], max4(qn.q0, qn.q1, qn.q2, qn.q3),
+                           done[i] != 0, lr, gamma);
+  rt_scatter(w, b_s, es, act, d);
+}
+
+__global__ __launch_bounds__(kBlock) void k_rt_fused_rollout(
+    uint8_t* boards, q2048_aux* aux, float* w, int64_t B, int steps, double eps, double lr,
+    double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, int64_t* stats_i, double* stats_f,
+    uint32_t* status) {
+  __shared__ BlockStats bs;
+  stats_clear(bs);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < B) {
+    Stage<4> st;
+    const uint64_t id = env_id0 + (uint64_t)i;
+    Board b = load_board(boards, i, B, st);
+    Aux a = ld_aux(aux, i);
+    uint32_t n_valid = 0, n_explore = 0, n_done = 0;
+    double reward_sum = 0.0;
+    for (int t = 0; t < steps; ++t) {
+      const Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
+      const Board s = b;
+      const RtRows es = rt_gather(w, s);
+      const Row q = rt_q(es);
+      bool explored;
+      const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);
+      const StepOut o = env_step(b, a, act, x.x2, x.x3);
+      const Row qn = rt_q(rt_gather(w, b));
+      const float d = rt_delta(row_get(q, act), o.reward, max4(qn.q0, qn.q1, qn.q2, qn.q3),
+                               o.done != 0, lr, gamma);
+      rt_scatter(w, s, es, act, d);
+      n_valid += wave_count(o.valid != 0);
+      n_explore += wave_count(explored);
+      n_done += wave_count(o.done != 0);
+      reward_sum += (double)o.reward;
+      if (o.done) {
+        episode_stats(bs, a, o.max_log2);
+        begin_episode(b, a, seed, id);
+      }
+    }
+    store_board(boards, i, B, b, st);
+    st_aux(aux, i, a);
+    atomicAdd(&bs.f[Q2048_SF_REWARD], reward_sum);
+    const uint32_t n_active = wave_count(true);
+    if (wave_leader()) {
+      atomicAdd(&bs.i[Q2048_ST_STEPS], (u64)n_active * (u64)steps);
+      atomicAdd(&bs.i[Q2048_ST_VALID], (u64)n_valid);
+      atomicAdd(&bs.i[Q2048_ST_EXPLORE], (u64)n_explore);
+      atomicAdd(&bs.i[Q2048_ST_EPISODES], (u64)n_done);
+    }
+  }
+  stats_flush(bs, stats_i, stats_f);
+}
+
+// ---------------------------------------------------------------------------------------------
 // table utilities
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_table_export(const q2048_slot* table, u64 cap,
@@ -779,6 +898,57 @@ int q2048_fused_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int 
   if (B == 0 || steps == 0) return Q2048_OK;
   Q2048_LAUNCH(k_fused_rollout, n, B, stream, boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B,
                (int)steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status);
+  return launch_status();
+}
+
+int q2048_rt_choose(const float* weights, const uint8_t* boards, int64_t B, double eps, uint64_t seed,
+                    uint64_t env_id0, uint32_t ctr, uint8_t* actions, void* stream) {
+  if (int e = check_batch(B, 4)) return e;
+  if (!weights || !boards || !actions) return Q2048_ERR_NULL;
+  if (!aligned16(weights) || !aligned16(boards)) return Q2048_ERR_ALIGN;
+  if (!(eps >= 0.0 && eps <= 1.0)) return Q2048_ERR_RANGE;
+  if (B == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_rt_choose, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, weights,
+                     boards, B, eps, seed, env_id0, ctr, actions);
+  return launch_status();
+}
+
+int q2048_rt_lookup(const float* weights, const uint8_t* boards, int64_t B, float* q_out, void* stream) {
+  if (int e = check_batch(B, 4)) return e;
+  if (!weights || !boards || !q_out) return Q2048_ERR_NULL;
+  if (!aligned16(weights) || !aligned16(boards) || !aligned16(q_out)) return Q2048_ERR_ALIGN;
+  if (B == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_rt_lookup, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, weights,
+                     boards, B, q_out);
+  return launch_status();
+}
+
+int q2048_rt_update(float* weights, const uint8_t* boards_s, const uint8_t* actions, const float* reward,
+                    const uint8_t* boards_s2, const uint8_t* done, int64_t B, double lr, double gamma,
+                    uint32_t* status, void* stream) {
+  if (int e = check_batch(B, 4)) return e;
+  if (!weights || !boards_s || !actions || !reward || !boards_s2 || !done || !status) return Q2048_ERR_NULL;
+  if (!aligned16(weights) || !aligned16(boards_s) || !aligned16(boards_s2)) return Q2048_ERR_ALIGN;
+  if (!(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
+  if (B == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_rt_update, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, weights,
+                     boards_s, actions, reward, boards_s2, done, B, lr, gamma, status);
+  return launch_status();
+}
+
+int q2048_rt_fused_rollout(uint8_t* boards, q2048_aux* aux, float* weights, int64_t B, int64_t steps,
+                           double eps, double lr, double gamma, uint64_t seed, uint64_t env_id0,
+                           uint32_t ctr0, int64_t* stats_i, double* stats_f, uint32_t* status,
+                           void* stream) {
+  if (int e = check_batch(B, 4)) return e;
+  if (!boards || !aux || !weights || !status) return Q2048_ERR_NULL;
+  if (!aligned16(boards) || !aligned16(aux) || !aligned16(weights)) return Q2048_ERR_ALIGN;
+  if (steps < 0 || steps > (1 << 30)) return Q2048_ERR_SIZE;
+  if (!(eps >= 0.0 && eps <= 1.0) || !(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
+  if (B == 0 || steps == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_rt_fused_rollout, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream,
+                     boards, aux, weights, B, (int)steps, eps, lr, gamma, seed, env_id0, ctr0, stats_i,
+                     stats_f, status);
   return launch_status();
 }
 

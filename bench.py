@@ -35,6 +35,9 @@ if REPO not in sys.path:
 
 ALGO_BYTES_FUSED_4X4 = 122  # SURVEY.md section 8(d) / BASELINE.md section 4
 ALGO_BYTES_FUSED_5X5 = 156
+# row-tuple learner: 64 B board+aux stream, 8 gathered 16-B entries, 4 weight writes, 6 B out.  The
+# 4 MiB weight table is cache-resident, so this figure is not HBM traffic.
+ALGO_BYTES_ROW_TUPLE = 64 + 8 * 16 + 4 * 4 + 6
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 
@@ -46,6 +49,9 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=64)
     p.add_argument("--boards-per-gpu", type=int, default=1 << 20)
     p.add_argument("--board-size", type=int, default=4, help="4 (BASELINE configs[2]/[3]) or 5 (configs[4])")
+    p.add_argument("--agent", choices=["hash", "row-tuple"], default="hash",
+                   help="hash = the reference's whole-board Q-table (headline); row-tuple = "
+                        "BASELINE configs[1] flat-array Q (use with --boards-per-gpu 65536)")
     p.add_argument("--steps-per-launch", type=int, default=64,
                    help="env steps per fused launch (boards stay in registers in between)")
     p.add_argument("--eps", type=float, default=0.95)
@@ -130,12 +136,19 @@ def main():
     cap_log2 = args.cap_log2 or table_capacity_log2(B, args.steps + args.warmup)
 
     algo_bytes = ALGO_BYTES_FUSED_4X4 if args.board_size == 4 else ALGO_BYTES_FUSED_5X5
+    if args.agent == "row-tuple":
+        algo_bytes = ALGO_BYTES_ROW_TUPLE
     env = pkg.BatchedGame2048Env(shard.num_envs, board_size=args.board_size, seed=args.seed,
                                  env_id0=shard.env_id0, device=dev)
-    agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
-                                      exploration_rate=args.eps, capacity_log2=cap_log2,
-                                      seed=args.seed, env_id0=shard.env_id0, device=dev,
-                                      strict_td=args.strict_td, board_size=args.board_size)
+    if args.agent == "row-tuple":
+        agent = pkg.BatchedRowTupleAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
+                                         exploration_rate=args.eps, seed=args.seed,
+                                         env_id0=shard.env_id0, device=dev)
+    else:
+        agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
+                                          exploration_rate=args.eps, capacity_log2=cap_log2,
+                                          seed=args.seed, env_id0=shard.env_id0, device=dev,
+                                          strict_td=args.strict_td, board_size=args.board_size)
 
     def run(steps):
         launches = 0
@@ -177,7 +190,7 @@ def main():
     avg_launch_s = (kernel_ms_max / 1e3) / launches
     algo_bytes_per_launch = algo_bytes * shard.num_envs * (args.steps / launches)
     achieved = algo_bytes_per_launch / avg_launch_s / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_fused_rollout", "achieved": achieved,
+    roofline = {"bound": "hbm", "kernel": "k_rt_fused_rollout" if args.agent == "row-tuple" else "k_fused_rollout", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                 "traffic": None,  # filled below from the committed PMC passes
@@ -186,7 +199,7 @@ def main():
                 "note": f"register-resident, K={S} env steps per launch: boards/aux cross HBM once "
                         f"per launch, the figure counts them once per step (SURVEY 8(d))"}
 
-    pmc = pmc_traffic_per_env_step() if args.board_size == 4 else None
+    pmc = pmc_traffic_per_env_step() if (args.board_size == 4 and args.agent == "hash") else None
     if pmc is not None:
         roofline["traffic"] = pmc["bytes_per_env_step"] * shard.num_envs * (args.steps / launches)
         roofline["traffic_source"] = pmc["source"]
@@ -197,8 +210,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": f"{B} parallel {args.board_size}x{args.board_size} boards per GPU (uint8 "
-                               f"log2), device open-addressed hash Q-table, fused step+select+TD kernel "
-                               f"(BASELINE configs[{2 if args.board_size == 4 else 4}]"
+                               f"log2), {'device open-addressed hash Q-table' if args.agent == 'hash' else 'flat-array row-tuple Q (4 MiB)'}, fused step+select+TD kernel "
+                               f"(BASELINE configs[{(2 if args.board_size == 4 else 4) if args.agent == 'hash' else 1}]"
                                f"{'' if world == 1 else '/[3] sharded, one Q replica per GPU'})",
                    "boards_per_gpu": B, "total_boards": shard.total_envs,
                    "steps_per_launch": S, "table_capacity_log2": cap_log2,

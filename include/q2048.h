@@ -184,6 +184,26 @@ int q2048_table_count(const q2048_slot *table, int cap_log2, int64_t *count, voi
 int q2048_table_export(const q2048_slot *table, int cap_log2, uint64_t *keys_out, float *q_out,
                        int64_t max_rows, int key_words, int64_t *count, void *stream);
 
+/* ---- row-tuple linear Q: BASELINE configs[1], "flat-array Q over row-tuple features" ----------
+ * NOT the reference's learner (its Q is keyed by the whole board, Agent/main.py:82) but the same
+ * loop with a different table: weights = float[4][65536][4] (16-byte aligned, zero = untrained),
+ * Q(s,a) = sum over rows r of weights[r][idx_r(s)][a], idx_r = the row's four log2 nibbles.
+ * Same epsilon-greedy / TD target as Agent/main.py:34-43; the error is spread evenly over the
+ * four weights, each written as (value read + delta) -- concurrent lanes race per weight and the
+ * last writer wins (summing all lanes' deltas would scale the step size by the batch size).
+ * 4x4 boards only. */
+int q2048_rt_choose(const float *weights, const uint8_t *boards, int64_t B, double eps,
+                    uint64_t seed, uint64_t env_id0, uint32_t ctr, uint8_t *actions, void *stream);
+int q2048_rt_lookup(const float *weights, const uint8_t *boards, int64_t B, float *q_out,
+                    void *stream);
+int q2048_rt_update(float *weights, const uint8_t *boards_s, const uint8_t *actions,
+                    const float *reward, const uint8_t *boards_s2, const uint8_t *done, int64_t B,
+                    double lr, double gamma, uint32_t *status, void *stream);
+int q2048_rt_fused_rollout(uint8_t *boards, q2048_aux *aux, float *weights, int64_t B,
+                           int64_t steps, double eps, double lr, double gamma, uint64_t seed,
+                           uint64_t env_id0, uint32_t ctr0, int64_t *stats_i, double *stats_f,
+                           uint32_t *status, void *stream);
+
 /* Inverse of q2048_table_export (resume / load a table trained elsewhere): inserts `rows`
  * (key, q[4]) pairs into the table, key_words as above.  A key already present has its row
  * overwritten; a row that finds no slot within the probe limit sets Q2048_STATUS_TABLE_FULL. */

@@ -105,6 +105,13 @@ def lib() -> C.CDLL:
                                C.c_uint32, u8p, i64p, f64p, u8p, f64p, u8p]),
         "orc_rollout_mt": (None, [vp, C.c_int64, C.POINTER(vp), C.c_int, C.c_int64,
                                   C.c_uint64, C.c_uint64, C.c_uint32, i64p, f64p]),
+        "orc_rt_new": (vp, []),
+        "orc_rt_free": (None, [vp]),
+        "orc_rt_q": (None, [vp, u8p, C.POINTER(C.c_float)]),
+        "orc_rt_choose": (C.c_int, [vp, u8p, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]),
+        "orc_rt_update": (None, [vp, u8p, C.c_int, C.c_float, u8p, C.c_int, C.c_double, C.c_double]),
+        "orc_rt_rollout": (None, [vp, C.c_int64, vp, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                  C.c_uint64, C.c_uint64, C.c_uint32, i64p, f64p]),
         "orc_sizeof_env": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -342,6 +349,49 @@ def rollout_mt(envs: np.ndarray, agents: list[Agent], steps: int, seed: int = 0,
     lib().orc_rollout_mt(envs.ctypes.data, len(envs), hs, T, steps, seed, env_id0,
                          ctr0 & 0xFFFFFFFF, _ptr(si, C.c_int64), _ptr(sf, C.c_double))
     return si, sf
+
+
+class RowTupleAgent:
+    """The row-tuple linear Q learner of BASELINE configs[1] (not in the reference)."""
+
+    def __init__(self, learning_rate=0.1, discount_factor=0.9, exploration_rate=1.0):
+        self.lr, self.gamma, self.epsilon = learning_rate, discount_factor, exploration_rate
+        self._w = lib().orc_rt_new()
+
+    def __del__(self):
+        if getattr(self, "_w", None) and _lib is not None:
+            _lib.orc_rt_free(self._w)
+            self._w = None
+
+    def _b(self, board):
+        b = np.zeros(MAXCELLS, dtype=np.uint8)
+        b[:16] = np.asarray(board, dtype=np.uint8).reshape(-1)
+        return b
+
+    def q(self, board) -> np.ndarray:
+        out = np.zeros(4, dtype=np.float32)
+        lib().orc_rt_q(self._w, _u8(self._b(board)), _ptr(out, C.c_float))
+        return out
+
+    def weights(self) -> np.ndarray:
+        buf = (C.c_float * (4 * 65536 * 4)).from_address(self._w)
+        return np.frombuffer(buf, dtype=np.float32).reshape(4, 65536, 4).copy()
+
+    def choose_action(self, board, draw_eps, draw_act) -> int:
+        return lib().orc_rt_choose(self._w, _u8(self._b(board)), self.epsilon, int(draw_eps),
+                                   int(draw_act), None)
+
+    def update_q_value(self, s, action, reward, s2, done):
+        lib().orc_rt_update(self._w, _u8(self._b(s)), int(action), float(reward), _u8(self._b(s2)),
+                            int(bool(done)), self.lr, self.gamma)
+
+    def rollout(self, envs: np.ndarray, steps: int, seed=0, env_id0=0, ctr0=0):
+        si = np.zeros(ST_NI, dtype=np.int64)
+        sf = np.zeros(SF_NF, dtype=np.float64)
+        lib().orc_rt_rollout(envs.ctypes.data, len(envs), self._w, steps, self.epsilon, self.lr,
+                             self.gamma, seed, env_id0, ctr0 & 0xFFFFFFFF, _ptr(si, C.c_int64),
+                             _ptr(sf, C.c_double))
+        return si, sf
 
 
 # ---- reference <-> oracle board conversion -------------------------------------------

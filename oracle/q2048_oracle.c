@@ -528,3 +528,99 @@ void orc_rollout_mt(orc_env_t *envs, int64_t B, orc_agent_t **agents, int T, int
   free(jobs);
   free(th);
 }
+
+/* ===================================================================================
+ * Row-tuple linear Q (BASELINE configs[1]) -- the build's own learner, see the header.
+ * =================================================================================== */
+#define ORC_RT_ROWS 4
+#define ORC_RT_IDX 65536
+
+float *orc_rt_new(void) { return (float *)calloc((size_t)ORC_RT_ROWS * ORC_RT_IDX * 4, sizeof(float)); }
+void orc_rt_free(float *w) { free(w); }
+
+static uint32_t orc_rt_index(const uint8_t *board, int r) {
+  const uint8_t *p = board + 4 * r;
+  return (uint32_t)(p[0] & 15) | ((uint32_t)(p[1] & 15) << 4) | ((uint32_t)(p[2] & 15) << 8) |
+         ((uint32_t)(p[3] & 15) << 12);
+}
+static float *orc_rt_entry(const float *w, int r, uint32_t idx) {
+  return (float *)w + (((size_t)r * ORC_RT_IDX + idx) << 2);
+}
+
+void orc_rt_q(const float *w, const uint8_t *board, float out[4]) {
+  const float *e0 = orc_rt_entry(w, 0, orc_rt_index(board, 0));
+  const float *e1 = orc_rt_entry(w, 1, orc_rt_index(board, 1));
+  const float *e2 = orc_rt_entry(w, 2, orc_rt_index(board, 2));
+  const float *e3 = orc_rt_entry(w, 3, orc_rt_index(board, 3));
+  for (int a = 0; a < 4; ++a) out[a] = (e0[a] + e1[a]) + (e2[a] + e3[a]);
+}
+
+int orc_rt_choose(const float *w, const uint8_t *board, double eps, uint32_t draw_eps,
+                  uint32_t draw_act, int *explored) {
+  if (orc_draw_uniform(draw_eps) < eps) {
+    if (explored) *explored = 1;
+    return orc_draw_action(draw_act);
+  }
+  if (explored) *explored = 0;
+  float q[4];
+  orc_rt_q(w, board, q);
+  int b = 0;
+  for (int a = 1; a < 4; ++a)
+    if (q[a] > q[b]) b = a;
+  return b;
+}
+
+void orc_rt_update(float *w, const uint8_t *s, int action, float reward, const uint8_t *s2,
+                   int done, double lr, double gamma) {
+  float qn[4], qs[4];
+  orc_rt_q(w, s2, qn);
+  orc_rt_q(w, s, qs);
+  float mx = qn[0] > qn[1] ? qn[0] : qn[1];
+  float m2 = qn[2] > qn[3] ? qn[2] : qn[3];
+  mx = mx > m2 ? mx : m2;
+  const double target = (double)reward + (gamma * (double)mx * (done ? 0.0 : 1.0));
+  const float d = (float)((lr * 0.25) * (target - (double)qs[action]));
+  for (int r = 0; r < ORC_RT_ROWS; ++r) orc_rt_entry(w, r, orc_rt_index(s, r))[action] += d;
+}
+
+void orc_rt_rollout(orc_env_t *envs, int64_t B, float *w, int64_t steps, double eps, double lr,
+                    double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0,
+                    int64_t *stats_i, double *stats_f) {
+  for (int64_t t = 0; t < steps; ++t) {
+    for (int64_t i = 0; i < B; ++i) {
+      orc_env_t *e = &envs[i];
+      const uint64_t id = env_id0 + (uint64_t)i;
+      uint32_t x[4];
+      orc_draws(seed, id, ctr0 + (uint32_t)t, ORC_STREAM_STEP, x);
+      uint8_t s[ORC_MAXCELLS];
+      memcpy(s, e->board, ORC_MAXCELLS);
+      int explored = 0;
+      const int a = orc_rt_choose(w, s, eps, x[0], x[1], &explored);
+      double r; int done, mx;
+      const int valid = orc_env_step(e, a, x[2], x[3], &r, &done, &mx);
+      orc_rt_update(w, s, a, (float)r, e->board, done, lr, gamma);
+      e->episode_return += (double)(float)r;
+      if (stats_i) {
+        stats_i[ORC_ST_STEPS] += 1;
+        stats_i[ORC_ST_VALID] += (valid > 0);
+        stats_i[ORC_ST_EXPLORE] += explored;
+      }
+      if (stats_f) stats_f[ORC_SF_REWARD] += (double)(float)r;
+      if (done) {
+        if (stats_i) {
+          stats_i[ORC_ST_EPISODES] += 1;
+          stats_i[ORC_ST_SCORE] += e->score;
+          stats_i[ORC_ST_HIST0 + (mx > 23 ? 23 : mx)] += 1;
+        }
+        if (stats_f) {
+          stats_f[ORC_SF_RETURN] += e->episode_return;
+          stats_f[ORC_SF_RETURN_SQ] += e->episode_return * e->episode_return;
+        }
+        uint32_t d[4];
+        e->episode += 1;
+        orc_draws(seed, id, e->episode, ORC_STREAM_RESET, d);
+        orc_env_reset(e, d);
+      }
+    }
+  }
+}

@@ -731,3 +731,60 @@ def test_export_dict_is_the_reference_table(pkg, O):
         state = tuple(tuple(int(x) for x in r) for r in pkg.boards_to_raw(k))
         assert state in d and d[state].dtype == np.float64
         assert np.allclose(d[state], v, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[1]: 65,536 boards, flat-array Q over row-tuple features.  Not the reference's
+# learner: checked against the oracle's own restatement of it.
+# ---------------------------------------------------------------------------------------------
+def test_row_tuple_single_env_matches_oracle(pkg, O):
+    """One env = the sequential learner: same actions, boards, weights (fused and 4-call API)."""
+    steps, seed, id0, eps, lr, gamma = 3000, 14, 555, 0.15, 0.1, 0.99
+    envs = O.envs_init(1, 4, seed, id0)
+    oa = O.RowTupleAgent(lr, gamma, eps)
+    si, sf = oa.rollout(envs, steps, seed, id0, 0)
+    for mode in ("fused", "unfused"):
+        env = pkg.BatchedGame2048Env(1, seed=seed, env_id0=id0, device=DEV)
+        agent = pkg.BatchedRowTupleAgent(100, learning_rate=lr, discount_factor=gamma,
+                                         exploration_rate=eps, seed=seed, env_id0=id0, device=DEV)
+        if mode == "fused":
+            for k in (1, 999, 2000):
+                agent.fused_rollout(env, k)
+        else:
+            _unfused_loop(pkg, env, agent, steps)
+        assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16]), mode
+        assert_aux(env.aux_fields(), envs, "row tuple " + mode)
+        w, ow = agent.weights.cpu().numpy(), oa.weights()
+        assert np.array_equal(w != 0, ow != 0), mode                 # same entries touched
+        assert np.allclose(w, ow, rtol=1e-5, atol=1e-6), mode
+        if mode == "fused":
+            st = agent.stats()
+            assert st["steps"] == steps and st["episodes"] == si[O.ST_EPISODES]
+            assert st["valid_moves"] == si[O.ST_VALID] and st["explored"] == si[O.ST_EXPLORE]
+        assert agent.check_status() == 0
+
+
+def test_row_tuple_65536_boards_properties(pkg, O):
+    """configs[1] size.  eps = 1: trajectories are exact whatever the racing weight writes do;
+    the weights stay bounded and track the sequential oracle's (same entries touched)."""
+    B, steps, seed = 65536, 64, 31
+    env = pkg.BatchedGame2048Env(B, seed=seed, device=DEV)
+    agent = pkg.BatchedRowTupleAgent(100, exploration_rate=1.0, learning_rate=0.05,
+                                     discount_factor=0.0, seed=seed, device=DEV)
+    agent.fused_rollout(env, steps)
+    envs = O.envs_init(B, 4, seed, 0)
+    oa = O.RowTupleAgent(0.05, 0.0, 1.0)
+    si, sf = oa.rollout(envs, steps, seed, 0, 0)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16])
+    st = agent.stats()
+    assert st["steps"] == B * steps and st["episodes"] == si[O.ST_EPISODES]
+    assert st["valid_moves"] == si[O.ST_VALID] and st["score_sum"] == si[O.ST_SCORE]
+    w, ow = agent.weights.cpu().numpy(), oa.weights()
+    assert np.array_equal(w != 0, ow != 0)              # exactly the same weights were touched
+    # every write is one valid TD step from a value some lane read (last writer wins), so the
+    # weights stay within the reward scale; the sequential oracle applies far more updates to the
+    # hot entries, so values are compared loosely
+    assert np.isfinite(w).all() and np.abs(w).max() <= 10.0
+    assert np.corrcoef(w.ravel(), ow.ravel())[0, 1] > 0.5
+    q = agent.q_values(env.boards[:1000]).cpu().numpy()
+    assert np.isfinite(q).all() and agent.check_status() == 0
