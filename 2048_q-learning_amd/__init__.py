@@ -11,14 +11,14 @@ csrc/libq2048_hip.so (built by __graft_entry__.build()); there is no CPU fallbac
 """
 from . import _native
 from ._native import NativeError, build
-from .agent import (BatchedQLearningAgent, BatchedRowTupleAgent, EpsilonSchedule, QLearningAgent,
-                    stats_dict)
+from .agent import (EPISODE_DTYPE, BatchedQLearningAgent, BatchedRowTupleAgent, EpisodeLog,
+                    EpsilonSchedule, QLearningAgent, stats_dict)
 from .dist import Shard, allreduce_stats, shard_plan, weak_shard
 from .env import (AUX_DTYPE, BatchedGame2048Env, Game2048_env, boards_to_raw, raw_to_boards)
 
 __all__ = [
     "BatchedGame2048Env", "Game2048_env", "BatchedQLearningAgent", "BatchedRowTupleAgent",
     "QLearningAgent",
-    "EpsilonSchedule", "stats_dict", "Shard", "shard_plan", "weak_shard", "allreduce_stats",
+    "EpsilonSchedule", "EpisodeLog", "EPISODE_DTYPE", "stats_dict", "Shard", "shard_plan", "weak_shard", "allreduce_stats",
     "boards_to_raw", "raw_to_boards", "AUX_DTYPE", "build", "NativeError",
 ]

@@ -23,7 +23,7 @@ FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
 ST_HIST0, NSTAT_I = 8, 32
 SF_RETURN, SF_RETURN_SQ, SF_REWARD, NSTAT_F = 0, 1, 2, 4
-SIZEOF_AUX, SIZEOF_SLOT = 16, 32
+SIZEOF_AUX, SIZEOF_SLOT, SIZEOF_EPISODE = 16, 32, 48
 
 
 class NativeError(RuntimeError):
@@ -91,6 +91,11 @@ _SIGNATURES = {
                                       C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double,
                                       C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "q2048_fused_rollout_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                          C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                          C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_void_p]),
     "q2048_table_count": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "q2048_rt_choose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_uint64,
                                   C.c_uint32, C.c_void_p, C.c_void_p]),

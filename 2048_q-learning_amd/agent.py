@@ -45,6 +45,37 @@ class EpsilonSchedule:
             self.epsilon = self.epsilon_min                                    # :57
 
 
+EPISODE_DTYPE = np.dtype([("env_id", "<u8"), ("episode", "<u4"), ("action", "u1"), ("max_log2", "u1"),
+                          ("steps_lo", "<u2"), ("reward", "<f4"), ("total_return", "<f4"),
+                          ("score", "<i4"), ("q", "<f4", (4,)), ("reserved", "<u4")])
+
+
+class EpisodeLog:
+    """Device buffer of finished-episode records (q2048_episode): the batched form of the rows
+    log_debug_info appends to debug_log.csv (Agent/main.py:59-62)."""
+
+    def __init__(self, capacity: int, device="cuda"):
+        self.device = _require_gpu(device)
+        self.capacity = int(capacity)
+        self.records = torch.zeros((self.capacity, N.SIZEOF_EPISODE), dtype=torch.uint8, device=self.device)
+        self.count = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    def drain(self) -> np.ndarray:
+        """Host copy of the records written so far (arrival order), then empties the log.
+        `lost` = episodes that finished while the buffer was full."""
+        n = int(self.count.item())
+        self.lost = max(0, n - self.capacity)
+        rec = self.records[: min(n, self.capacity)].cpu().numpy().view(EPISODE_DTYPE).reshape(-1).copy()
+        self.count.zero_()
+        return rec
+
+    @staticmethod
+    def csv_row(rec) -> list:
+        """One record in the reference's column order (Agent/main.py:62)."""
+        return [int(rec["episode"]), int(rec["action"]), np.asarray(rec["q"], dtype=np.float64),
+                float(rec["reward"]), float(rec["total_return"]), 1 << int(rec["max_log2"])]
+
+
 class _QTableView:
     """`agent.q_table[state]` (Agent/main.py:16,96): state = tuple of 4 tuples of raw tile
     values; returns the 4 Q-values as float64 (zeros when the state was never updated)."""
@@ -159,10 +190,11 @@ class BatchedQLearningAgent:
         return (q, found.bool()) if return_found else q
 
     # -- throughput entry point ----------------------------------------------------------
-    def fused_rollout(self, env: BatchedGame2048Env, steps: int) -> None:
+    def fused_rollout(self, env: BatchedGame2048Env, steps: int, episode_log: "EpisodeLog | None" = None) -> None:
         """`steps` iterations of choose -> step -> update -> accumulate -> reset-on-done
         (Agent/main.py:91-101, :81) for every env in ONE launch.  Statistics accumulate in
-        `stats_i` / `stats_f` on the device (read them with `stats()`)."""
+        `stats_i` / `stats_f` on the device (read them with `stats()`); with `episode_log` every
+        finished episode also leaves one record (the reference's CSV row, :103-105)."""
         if env.device != self.device:
             raise ValueError("env and agent live on different devices")
         if (env.seed, env.env_id0) != (self.seed, self.env_id0):
@@ -171,12 +203,14 @@ class BatchedQLearningAgent:
             raise ValueError("env and agent have different board sizes")
         if env.ctr != self.ctr:
             raise ValueError(f"env.ctr={env.ctr} and agent.ctr={self.ctr} are out of step")
-        N.check(N.lib().q2048_fused_rollout(
+        log = episode_log
+        N.check(N.lib().q2048_fused_rollout_log(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
             self.board_size, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
             self.env_id0, self.ctr & 0xFFFFFFFF, self.flags | self.experiment_bits,
-            _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status), _stream(self.device)),
-            "fused_rollout")
+            _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status),
+            _ptr(log.records) if log is not None else None, log.capacity if log is not None else 0,
+            _ptr(log.count) if log is not None else None, _stream(self.device)), "fused_rollout")
         env.ctr += int(steps)
         self.ctr += int(steps)
 

@@ -25,6 +25,7 @@ constexpr int kMaxProbe = 256;   // probe limit: beyond it a lookup reads "absen
 constexpr int kMaxCas = 4096;    // TD compare-and-swap retries before the additive fallback
 
 static_assert(sizeof(q2048_aux) == 16 && sizeof(q2048_slot) == 32, "ABI layout");
+static_assert(sizeof(q2048_episode) == 48, "ABI layout");
 static_assert(sizeof(Aux) == sizeof(q2048_aux), "core/ABI aux mismatch");
 
 using u64 = unsigned long long;
@@ -477,7 +478,8 @@ template <int N>
 __global__ __launch_bounds__(kBlock) void k_fused_rollout(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
     double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
-    int64_t* stats_i, double* stats_f, uint32_t* status) {
+    int64_t* stats_i, double* stats_f, uint32_t* status, q2048_episode* log, int64_t log_cap,
+    u64* log_count) {
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
   stats_clear(bs);
@@ -530,6 +532,20 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
         if (!same && slot_n < 0 && slot_n != kNoSlot && !x_noclaim)
           probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
         episode_stats(bs, a, o.max_log2);
+        if (log != nullptr) {                                                          // :59-62, :105
+          const u64 at = atomicAdd(log_count, 1ull);
+          if ((int64_t)at < log_cap) {
+            Row ql = q;
+            if (updated) row_set(ql, act, nq);   // the logged row is the live one (:96), post-update
+            q2048_episode rec;
+            rec.env_id = id; rec.episode = a.episode; rec.action = (uint8_t)act;
+            rec.max_log2 = o.max_log2; rec.steps_lo = (uint16_t)(ctr0 + (uint32_t)t);
+            rec.reward = o.reward; rec.total_return = a.ep_return; rec.score = a.score;
+            rec.q[0] = ql.q0; rec.q[1] = ql.q1; rec.q[2] = ql.q2; rec.q[3] = ql.q3;
+            rec.reserved = 0u;
+            log[at] = rec;
+          }
+        }
         begin_episode(b, a, seed, id);                                                 // :81
         key_s = state_key(b, salt, status);
         bool made = false;
@@ -889,7 +905,19 @@ int q2048_fused_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int 
                         int n, int64_t steps, double eps, double lr, double gamma, uint64_t seed,
                         uint64_t env_id0, uint32_t ctr0, uint32_t flags, int64_t* stats_i,
                         double* stats_f, uint32_t* status, void* stream) {
+  return q2048_fused_rollout_log(boards, aux, table, cap_log2, B, n, steps, eps, lr, gamma, seed,
+                                 env_id0, ctr0, flags, stats_i, stats_f, status, nullptr, 0, nullptr,
+                                 stream);
+}
+
+int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2,
+                            int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
+                            uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
+                            int64_t* stats_i, double* stats_f, uint32_t* status, q2048_episode* log,
+                            int64_t log_capacity, uint64_t* log_count, void* stream) {
   if (int e = check_batch(B, n)) return e;
+  if (log != nullptr && (log_count == nullptr || log_capacity < 0)) return Q2048_ERR_NULL;
+  if (log != nullptr && !aligned16(log)) return Q2048_ERR_ALIGN;
   if (int e = check_table(table, cap_log2)) return e;
   if (!boards || !aux || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
@@ -897,7 +925,8 @@ int q2048_fused_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int 
   if (!(eps >= 0.0 && eps <= 1.0) || !(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
   if (B == 0 || steps == 0) return Q2048_OK;
   Q2048_LAUNCH(k_fused_rollout, n, B, stream, boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B,
-               (int)steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status);
+               (int)steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status, log,
+               log_capacity, reinterpret_cast<u64*>(log_count));
   return launch_status();
 }
 

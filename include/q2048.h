@@ -82,6 +82,21 @@ typedef struct q2048_slot {
                         5x5: bits 63..124 of the key | bit 63, published right after `key` */
 } q2048_slot;
 
+/* one finished episode = one row of the reference's debug_log.csv (Agent/main.py:59-62,71-76:
+ * Episode, Action, Q-Values, Reward, Total-Reward, Max Value), written by q2048_fused_rollout_log */
+typedef struct q2048_episode {
+  uint64_t env_id;    /* global env id */
+  uint32_t episode;   /* index of the finished episode within that env ("Episode") */
+  uint8_t action;     /* last action ("Action") */
+  uint8_t max_log2;   /* log2 of the max tile of the final board ("Max Value" = 2^max_log2) */
+  uint16_t steps_lo;  /* low 16 bits of the global step counter at which the episode ended */
+  float reward;       /* last reward ("Reward") */
+  float total_return; /* sum of the episode's rewards ("Total-Reward") */
+  int32_t score;      /* env.score at the end */
+  float q[4];         /* post-update Q row of the last state ("Q-Values", main.py:96 aliases the row) */
+  uint32_t reserved;
+} q2048_episode;
+
 /* indices of the statistics vectors (device int64[Q2048_NSTAT_I], double[Q2048_NSTAT_F]);
  * kernels ADD to them, the caller zeroes them */
 enum {
@@ -173,6 +188,17 @@ int q2048_fused_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int 
                         int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
                         uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
                         int64_t *stats_i, double *stats_f, uint32_t *status, void *stream);
+
+/* q2048_fused_rollout that also appends one q2048_episode record per finished episode to
+ * log[0 .. log_capacity) (log_count is a device uint64 cursor the caller zeroes; records beyond
+ * the capacity are counted but not written).  This is the device form of log_debug_info
+ * (Agent/main.py:59-62, called at :103-105). */
+int q2048_fused_rollout_log(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2,
+                            int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
+                            uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
+                            int64_t *stats_i, double *stats_f, uint32_t *status,
+                            q2048_episode *log, int64_t log_capacity, uint64_t *log_count,
+                            void *stream);
 
 /* len(agent.q_table): adds the number of occupied slots to *count (device int64). */
 int q2048_table_count(const q2048_slot *table, int cap_log2, int64_t *count, void *stream);

@@ -788,3 +788,61 @@ def test_row_tuple_65536_boards_properties(pkg, O):
     assert np.corrcoef(w.ravel(), ow.ravel())[0, 1] > 0.5
     q = agent.q_values(env.boards[:1000]).cpu().numpy()
     assert np.isfinite(q).all() and agent.check_status() == 0
+
+
+def test_episode_log_matches_reference_csv_rows(pkg):
+    """The device episode log against the reference's own transcript (golden G6: 30 episodes of
+    Agent/main.py:80-109 with the draws injected): one record per finished episode carrying the
+    columns of debug_log.csv (main.py:62) -- Episode, Action, Q-Values, Reward, Total-Reward,
+    Max Value -- plus the epsilon schedule applied per episode (:109)."""
+    g = load_npz("g6_episodes_seed0.npz")
+    seed, id0, E = int(g["seed"]), int(g["env_id0"]), int(g["E"])
+    env = pkg.BatchedGame2048Env(1, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(E, learning_rate=float(g["lr"]), discount_factor=float(g["gamma"]),
+                                      exploration_rate=float(g["eps0"]), capacity_log2=16, seed=seed,
+                                      env_id0=id0, device=DEV)
+    log = pkg.EpisodeLog(64, device=DEV)
+    finished, recs, eps_trace, last_rows = 0, [], [], []
+    for t in range(int(g["steps"])):
+        prev = env.boards.clone()
+        agent.fused_rollout(env, 1, episode_log=log)
+        if int(log.count.item()) > 0:
+            r = log.drain()
+            assert len(r) == 1
+            recs.append(r[0])
+            last_rows.append(agent.q_values(prev).cpu().numpy()[0])
+            agent.decay_exploration(finished)                           # Agent/main.py:109
+            eps_trace.append(agent.epsilon)
+            finished += 1
+    ends = np.flatnonzero(g["dones"])
+    assert finished == len(ends) == len(g["ep_returns"])
+    assert np.array_equal(np.array(eps_trace), g["eps_trace"])          # bit-identical schedule
+    for e, (rec, idx) in enumerate(zip(recs, ends)):
+        row = pkg.EpisodeLog.csv_row(rec)
+        assert row[0] == e and rec["env_id"] == id0
+        assert row[1] == g["actions"][idx]                              # Action
+        assert np.float32(row[3]) == np.float32(g["rewards"][idx])      # Reward
+        assert np.isclose(row[4], g["ep_returns"][e], rtol=1e-5)        # Total-Reward
+        assert row[5] == g["maxes"][idx]                                # Max Value
+        assert rec["score"] == g["ep_scores"][e]
+        assert np.array_equal(np.asarray(rec["q"]), last_rows[e])       # Q-Values = live row of `state`
+    assert np.array_equal(env.boards.cpu().numpy(), g["final_boards"])
+    # the whole Q-table of the run against the reference's dict
+    got = agent.q_values(t8(g["q_keys"])).cpu().numpy()
+    assert np.allclose(got, g["q_vals"], rtol=1e-5, atol=1e-6) and agent.table_size() == len(g["q_keys"])
+
+
+def test_episode_log_batched_overflow_and_order(pkg):
+    B, steps = 2048, 400
+    env = pkg.BatchedGame2048Env(B, seed=3, device=DEV)
+    agent = pkg.BatchedQLearningAgent(10, exploration_rate=1.0, capacity_log2=22, seed=3, device=DEV)
+    log = pkg.EpisodeLog(1000, device=DEV)
+    agent.fused_rollout(env, steps, episode_log=log)
+    st = agent.stats()
+    rec = log.drain()
+    assert st["episodes"] > 1000 and len(rec) == 1000 and log.lost == st["episodes"] - 1000
+    assert rec["env_id"].max() < B and np.all(rec["total_return"] != 0)
+    # per env, records arrive in episode order
+    for e in np.unique(rec["env_id"])[:50]:
+        ep = rec["episode"][rec["env_id"] == e]
+        assert np.all(np.diff(ep.astype(np.int64)) > 0)

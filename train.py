@@ -48,6 +48,8 @@ def parse_args(argv=None):
     p.add_argument("--log", default="debug_log.csv", help="CSV log path (Agent/main.py:71)")
     p.add_argument("--report-every", type=int, default=10, help="launches between CSV rows (batched)")
     p.add_argument("--max-steps", type=int, default=0, help="stop after this many env steps per env (0 = off)")
+    p.add_argument("--episode-log", default="", help="batched mode: also write one row per finished "
+                   "episode with the reference's columns (Agent/main.py:71-76) + Env to this CSV")
     return p.parse_args(argv)
 
 
@@ -116,12 +118,24 @@ def train_batched(args, pkg):
         with open(args.log, mode="w", newline="") as fh:
             csv.writer(fh).writerow(["Epoch", "Episodes", "Env-Steps", "Epsilon", "Mean-Return",
                                      "Mean-Score", "Max Value", "Table-Rows", "Drops", "Steps/s"])
+    ep_log = None
+    if args.episode_log:
+        ep_log = pkg.EpisodeLog(max(4 * B, 1 << 16), device=dev)
+        ep_path = args.episode_log if world == 1 else f"{args.episode_log}.rank{rank}"
+        with open(ep_path, mode="w", newline="") as fh:
+            csv.writer(fh).writerow(["Episode", "Action", "Q-Values", "Reward", "Total-Reward",
+                                     "Max Value", "Env"])
     total_eps, epoch, launches, t0 = 0, 0, 0, time.time()
     target = args.episodes * shard.total_envs
     best_tile = 0
     while total_eps < target:
-        agent.fused_rollout(env, args.steps_per_launch)
+        agent.fused_rollout(env, args.steps_per_launch, episode_log=ep_log)
         launches += 1
+        if ep_log is not None:
+            with open(ep_path, mode="a", newline="") as fh:      # log_debug_info, Agent/main.py:59-62
+                wr = csv.writer(fh)
+                for rec in ep_log.drain():
+                    wr.writerow(pkg.EpisodeLog.csv_row(rec) + [int(rec["env_id"])])
         if launches % args.report_every and not args.max_steps:
             continue
         si, sf = agent.stats_i.clone(), agent.stats_f.clone()
