@@ -190,6 +190,34 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
   return kNoSlot;
 }
 
+// 4x4 lookup.  The cost of the table is the NUMBER of scattered requests (measured: ~8 us per
+// million loads, ~11 per million stores, ~25 per million atomics, whatever line they hit), so the
+// probe reads {key, q0, q1} with ONE 16-byte load and fetches {q2, q3} only on a hit.  The load
+// carries sc1 like the agent-scope 8-byte loads it replaces (bypasses the per-CU L1, keeps the
+// default L2 / Infinity Cache policy: a non-temporal load made the next step's claim of the same
+// line twice as slow).
+__device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
+                                              const Geo<4>::Key& key, Row& row, bool& created) {
+  u64 i = key_home(key, mask);
+  created = false;
+  row = Row{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < kMaxProbe; ++p) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;  // agent-scope (sc1: L1-bypassing, default L2 policy) 16-byte load; waited for in place
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=v"(v) : "v"(&table[i]) : "memory");
+    const u64 k = (u64)v.x | ((u64)v.y << 32);
+    if (k == key.k0) {
+      const u64 hi = ld_u64(&table[i].q[2]);
+      row = Row{bits_f32(v.z), bits_f32(v.w), bits_f32((uint32_t)hi), bits_f32((uint32_t)(hi >> 32))};
+      return (int64_t)i;
+    }
+    if (k == 0ull) return ~(int64_t)i;
+    i = (i + 1ull) & mask;
+  }
+  return kNoSlot;
+}
+
 // Find-or-create starting at slot `start` (the hint of a failed probe_find, or the home slot).
 // The first access is the claiming compare-and-swap itself: the slot was empty a moment ago.
 // Returns the slot index or kNoSlot (probe limit: the caller drops the update).
