@@ -395,6 +395,43 @@ __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux*
   store_board(boards, i, B, b, st);
 }
 
+// legal-move mask (mainDQL_CNN_step2.py:168-174): four trial moves per lane, nothing stored back
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_legal_moves(const uint8_t* boards, int64_t B, uint8_t* mask_out) {
+  __shared__ Stage<N> st;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const auto b = load_board(boards, i, B, st);
+  if (i >= B) return;
+  uint32_t m = 0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    auto t = b;
+    uint32_t score;
+    m |= (uint32_t)move(t, a, score) << a;
+  }
+  mask_out[i] = (uint8_t)m;
+}
+
+// one-hot encoder (Dqn8TestNOPERCNN.py:271-277): thread = (board, channel, row) -> 4 outputs;
+// the 1 KiB (f32) / 512 B (bf16) image of a board is written by 64 consecutive threads
+template <bool BF16>
+__global__ __launch_bounds__(kBlock) void k_encode_onehot(const uint8_t* boards, int64_t B, void* out) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= B * 64) return;
+  const int64_t b = t >> 6;
+  const uint32_t c = (uint32_t)(t >> 2) & 15u, r = (uint32_t)t & 3u;
+  const uint32_t w = reinterpret_cast<const uint32_t*>(boards)[b * 4 + r];  // row r: 4 tile bytes
+  const bool h0 = (w & 0xffu) == c, h1 = ((w >> 8) & 0xffu) == c, h2 = ((w >> 16) & 0xffu) == c,
+             h3 = (w >> 24) == c;
+  if constexpr (BF16) {  // bf16 1.0 = 0x3F80
+    reinterpret_cast<uint2*>(out)[t] = make_uint2((h0 ? 0x3F80u : 0u) | (h1 ? 0x3F800000u : 0u),
+                                                  (h2 ? 0x3F80u : 0u) | (h3 ? 0x3F800000u : 0u));
+  } else {
+    reinterpret_cast<float4*>(out)[t] = make_float4(h0 ? 1.f : 0.f, h1 ? 1.f : 0.f, h2 ? 1.f : 0.f,
+                                                    h3 ? 1.f : 0.f);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // agent kernels
 // ---------------------------------------------------------------------------------------------
@@ -955,6 +992,29 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
   Q2048_LAUNCH(k_fused_rollout, n, B, stream, boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B,
                (int)steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status, log,
                log_capacity, reinterpret_cast<u64*>(log_count));
+  return launch_status();
+}
+
+int q2048_legal_moves(const uint8_t* boards, int64_t B, int n, uint8_t* mask_out, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (!boards || !mask_out) return Q2048_ERR_NULL;
+  if (!aligned16(boards)) return Q2048_ERR_ALIGN;
+  if (B == 0) return Q2048_OK;
+  Q2048_LAUNCH(k_legal_moves, n, B, stream, boards, B, mask_out);
+  return launch_status();
+}
+
+int q2048_encode_onehot(const uint8_t* boards, int64_t B, int dtype, void* out, void* stream) {
+  if (int e = check_batch(B, 4)) return e;
+  if (!boards || !out) return Q2048_ERR_NULL;
+  if (!aligned16(boards) || !aligned16(out)) return Q2048_ERR_ALIGN;
+  if (dtype != 0 && dtype != 1) return Q2048_ERR_RANGE;
+  if (B == 0) return Q2048_OK;
+  const unsigned grid = (unsigned)((B * 64 + kBlock - 1) / kBlock);
+  if (dtype == 0)
+    hipLaunchKernelGGL(k_encode_onehot<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, boards, B, out);
+  else
+    hipLaunchKernelGGL(k_encode_onehot<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, boards, B, out);
   return launch_status();
 }
 

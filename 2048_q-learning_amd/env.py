@@ -104,6 +104,27 @@ class BatchedGame2048Env:
     def max_log2(self) -> torch.Tensor:
         return self._max
 
+    # -- bridges to the reference's DQN front-end ------------------------
+    def legal_moves(self) -> torch.Tensor:
+        """uint8 [B]: bit a set iff action a would change the board -- the trial-move loop of
+        Deep_QLearning/main_dir/mainDQL_CNN_step2.py:168-174."""
+        mask = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        N.check(N.lib().q2048_legal_moves(_ptr(self.boards), self.num_envs, self.board_size,
+                                          _ptr(mask), _stream(self.device)), "legal_moves")
+        return mask
+
+    def encode_onehot(self, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """[B, 16, 4, 4] one-hot of the log2 tiles (Dqn8TestNOPERCNN.py:271-277); 4x4 only."""
+        if self.board_size != 4:
+            raise ValueError("the one-hot encoder is defined for 4x4 boards")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("dtype must be float32 or bfloat16")
+        out = torch.empty((self.num_envs, 16, 4, 4), dtype=dtype, device=self.device)
+        N.check(N.lib().q2048_encode_onehot(_ptr(self.boards), self.num_envs,
+                                            0 if dtype == torch.float32 else 1, _ptr(out),
+                                            _stream(self.device)), "encode_onehot")
+        return out
+
     # -- checkpoint ---------------------------------------------------------------------------
     def state_dict(self) -> dict:
         """Everything needed to continue this batch bit-exactly (host tensors)."""

@@ -210,6 +210,18 @@ int q2048_table_count(const q2048_slot *table, int cap_log2, int64_t *count, voi
 int q2048_table_export(const q2048_slot *table, int cap_log2, uint64_t *keys_out, float *q_out,
                        int64_t max_rows, int key_words, int64_t *count, void *stream);
 
+/* Legal-move mask: bit a of mask_out[i] is set iff action a would change board i -- the trial-move
+ * loop of Deep_QLearning/main_dir/mainDQL_CNN_step2.py:168-174 (`env.game.move(action,
+ * trial=True)`), the reference's way of listing legal moves.  No board is modified. */
+int q2048_legal_moves(const uint8_t *boards, int64_t B, int n, uint8_t *mask_out, void *stream);
+
+/* One-hot state encoder of the reference's DQN front-end (Deep_QLearning/main_dir/
+ * Dqn8TestNOPERCNN.py:271-277: one_hot(log2(tile), depth 16) transposed to [16, 4, 4]):
+ * out[i][c][r][col] = 1 if the log2 tile at (r, col) equals c (empty cells are channel 0, tiles
+ * of 2^16 and above encode as all zeros, as tf.one_hot does), else 0.  4x4 boards;
+ * out is float32 (dtype = 0) or bfloat16 (dtype = 1), 16-byte aligned, [B][16][4][4]. */
+int q2048_encode_onehot(const uint8_t *boards, int64_t B, int dtype, void *out, void *stream);
+
 /* ---- row-tuple linear Q: BASELINE configs[1], "flat-array Q over row-tuple features" ----------
  * NOT the reference's learner (its Q is keyed by the whole board, Agent/main.py:82) but the same
  * loop with a different table: weights = float[4][65536][4] (16-byte aligned, zero = untrained),

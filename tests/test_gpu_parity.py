@@ -846,3 +846,47 @@ def test_episode_log_batched_overflow_and_order(pkg):
     for e in np.unique(rec["env_id"])[:50]:
         ep = rec["episode"][rec["env_id"] == e]
         assert np.all(np.diff(ep.astype(np.int64)) > 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# bridges to the reference's DQN front-end
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [4, 5])
+def test_legal_moves_mask(pkg, O, n):
+    """bit a == "move a changes the board", i.e. the reference's trial-move loop
+    (mainDQL_CNN_step2.py:168-174), against the oracle's move()."""
+    B = 3000
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=8, device=DEV)
+    acts = torch.randint(0, 4, (B,), dtype=torch.uint8, device=DEV)
+    for _ in range(60):                       # mid-game boards, some of them stuck in a direction
+        env.step(acts)
+    before = env.boards.clone()
+    mask = env.legal_moves().cpu().numpy()
+    assert torch.equal(before, env.boards)    # a probe, nothing is modified
+    boards = before.cpu().numpy()
+    want = np.array([sum(int(O.move(b, a, n=n)[2]) << a for a in range(4)) for b in boards], np.uint8)
+    assert np.array_equal(mask, want) and len(set(want.tolist())) > 4
+    g = load_npz("g3_game_over.npz")          # dead boards of the reference: no legal move
+    if n == 4:
+        e2 = pkg.BatchedGame2048Env(len(g["boards"]), seed=0, device=DEV)
+        e2.boards.copy_(t8(g["boards"]))
+        m2 = e2.legal_moves().cpu().numpy()
+        full = (g["boards"] != 0).all(axis=1)
+        assert np.array_equal((m2 == 0) & full, g["over"].astype(bool))
+
+
+def test_encode_onehot_matches_reference_encoder(pkg):
+    """Dqn8TestNOPERCNN.py:271-277 restated in numpy: one_hot(log2 tile, depth 16) as [16,4,4]."""
+    B = 1000
+    env = pkg.BatchedGame2048Env(B, seed=2, device=DEV)
+    acts = torch.randint(0, 4, (B,), dtype=torch.uint8, device=DEV)
+    for _ in range(80):
+        env.step(acts)
+    env.boards[0, 5] = 16                     # a 2^16 tile: tf.one_hot(16, depth=16) is all zeros
+    boards = env.boards.cpu().numpy()
+    want = (boards[:, None, :] == np.arange(16, dtype=np.uint8)[None, :, None]).reshape(B, 16, 4, 4)
+    f32 = env.encode_onehot().cpu().numpy()
+    assert f32.dtype == np.float32 and np.array_equal(f32, want.astype(np.float32))
+    assert f32[0, :, 1, 1].sum() == 0 and np.all(f32[1:].sum(axis=1) == 1)
+    bf = env.encode_onehot(torch.bfloat16)
+    assert bf.dtype == torch.bfloat16 and np.array_equal(bf.float().cpu().numpy(), want.astype(np.float32))
