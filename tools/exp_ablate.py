@@ -4,7 +4,7 @@ import gc, importlib, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
-MODES = {"store_plain": 0, "cas": 1, "store_sc1": 2, "none": 4}
+MODES = {"store_plain": 0, "cas": 1, "store_sc1": 2, "add": 6, "none": 4}
 
 def run(name, bits, B=1 << 20, S=16, steps=128, warm=64, eps=0.95, cap_log2=29, warm_bits=None):
     env = pkg.BatchedGame2048Env(B, seed=0, device="cuda:0")

@@ -8,7 +8,7 @@ for d in sorted(glob.glob(os.path.join(root, "pass*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r.get("Kernel_Name", "")
-            short = name.replace("(anonymous namespace)::", "").split("(")[0][-40:]
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-40:]
             acc[(short, r.get("Counter_Name"))].append((int(r.get("Dispatch_Id", 0)), float(r.get("Counter_Value", 0))))
     print("==", os.path.basename(d))
     for (k, c), v in sorted(acc.items()):

@@ -23,10 +23,13 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCC_EA0_ATOMIC_sum" "TCC_HIT_sum TCC_MISS_su
 done
 python3 tools/pmc_summary.py "$OUT/pmc" 1048576 64 | tee "$OUT/pmc/summary.txt"
 echo "== bench variants"
-for extra in "--strict-td" "--eps 0.01" "--eps 0.01 --strict-td" "--steps-per-launch 1 --steps 64" "--steps-per-launch 16" "--boards-per-gpu 65536 --steps 512"; do
+for extra in "--strict-td" "--eps 0.01" "--eps 0.01 --strict-td" "--steps-per-launch 1 --steps 64" "--steps-per-launch 16" "--boards-per-gpu 65536 --steps 512" "--board-size 5" "--agent row-tuple --boards-per-gpu 65536 --steps 512" "--agent row-tuple"; do
   echo "-- $extra"
-  timeout -k 10 300 python bench.py --cpu-seconds 0 $extra 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({k:d[k] for k in ('value','ms_per_step')}|{'frac':d['roofline']['frac'],'retries':d['stats']['cas_retries'],'drops':d['stats']['drops']}))" | tee -a "$OUT/variants.jsonl"; rc=${PIPESTATUS[0]}; bad $rc && exit 1
+  timeout -k 10 300 python bench.py --cpu-seconds 0 $extra 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'args':sys.argv[1]}|{k:d[k] for k in ('value','ms_per_step')}|{'frac':d['roofline']['frac'],'retries':d['stats']['cas_retries'],'drops':d['stats']['drops']}))" "$extra" | tee -a "$OUT/variants.jsonl"; rc=${PIPESTATUS[0]}; bad $rc && exit 1
 done
+echo "== ablation + env-only kernel"
+timeout -k 10 600 python tools/exp_ablate.py 2> /dev/null | tee "$OUT/ablate.jsonl"
+timeout -k 10 300 python tools/exp_variants.py 2> /dev/null | head -n 2 | tee "$OUT/env_only.jsonl"
 echo "== train.py smoke"
 timeout -k 10 300 python train.py --num-envs 1 --episodes 3 --log "$OUT/train_single.csv" 2>&1 | tail -n 3
 timeout -k 10 300 python train.py --num-envs 65536 --episodes 3 --steps-per-launch 32 --report-every 4 --log "$OUT/train_batched.csv" 2>&1 | tail -n 4
