@@ -120,6 +120,8 @@ def cpu_baseline(args, seconds: float) -> dict:
 
 def main():
     args = parse_args()
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
     pkg = importlib.import_module("2048_q-learning_amd")
     rank, local_rank, world = pkg.dist.init_process_group()
     if world != args.gpus:

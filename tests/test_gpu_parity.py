@@ -890,3 +890,40 @@ def test_encode_onehot_matches_reference_encoder(pkg):
     assert f32[0, :, 1, 1].sum() == 0 and np.all(f32[1:].sum(axis=1) == 1)
     bf = env.encode_onehot(torch.bfloat16)
     assert bf.dtype == torch.bfloat16 and np.array_equal(bf.float().cpu().numpy(), want.astype(np.float32))
+
+
+def test_tile_overflow_is_reported(pkg):
+    """A tile above 2^15 does not fit the 64-bit state key: the status word says so (the env
+    itself keeps playing exactly; only the agent's key aliases)."""
+    env = pkg.BatchedGame2048Env(64, seed=1, device=DEV)
+    agent = pkg.BatchedQLearningAgent(10, exploration_rate=1.0, capacity_log2=12, seed=1, device=DEV)
+    board = np.zeros(16, dtype=np.uint8)
+    board[0] = board[1] = 15                       # two 32768 tiles: moving left makes 65536
+    env.boards[7].copy_(torch.from_numpy(board).to(DEV))
+    acts = torch.zeros(64, dtype=torch.uint8, device=DEV)
+    _, r, d, mx = env.step(acts)
+    assert int(env.boards[7, 0]) == 16 and int(mx[7]) == 65536 and int(env.score[7]) == 65536
+    assert agent.check_status() == 0
+    agent.q_values(env.boards)
+    assert agent.check_status() & pkg._native.STATUS_TILE_OVERFLOW
+
+
+def test_steps_counter_and_argument_checks(pkg):
+    env = pkg.BatchedGame2048Env(8, seed=1, device=DEV)
+    agent = pkg.BatchedQLearningAgent(10, capacity_log2=10, seed=1, device=DEV)
+    agent.fused_rollout(env, 3)
+    assert (env.ctr, agent.ctr) == (3, 3)
+    env.step(torch.zeros(8, dtype=torch.uint8, device=DEV))
+    with pytest.raises(ValueError, match="out of step"):
+        agent.fused_rollout(env, 1)
+    other = pkg.BatchedQLearningAgent(10, capacity_log2=10, seed=2, device=DEV)
+    with pytest.raises(ValueError, match="share seed"):
+        other.fused_rollout(pkg.BatchedGame2048Env(8, seed=1, device=DEV), 1)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(7, dtype=torch.uint8, device=DEV))
+    with pytest.raises(ValueError):
+        agent.q_values(torch.zeros((4, 25), dtype=torch.uint8, device=DEV))
+    with pytest.raises(pkg.NativeError):
+        pkg._native.check(pkg._native.lib().q2048_fused_rollout(
+            env.boards.data_ptr(), env.aux.data_ptr(), agent.table.data_ptr(), agent.capacity_log2, 8, 4,
+            -1, 0.5, 0.1, 0.9, 0, 0, 0, 0, None, None, agent.status.data_ptr(), None), "neg steps")
