@@ -927,3 +927,41 @@ def test_steps_counter_and_argument_checks(pkg):
         pkg._native.check(pkg._native.lib().q2048_fused_rollout(
             env.boards.data_ptr(), env.aux.data_ptr(), agent.table.data_ptr(), agent.capacity_log2, 8, 4,
             -1, 0.5, 0.1, 0.9, 0, 0, 0, 0, None, None, agent.status.data_ptr(), None), "neg steps")
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_shared_table_writes_are_legitimate_values(pkg, O, strict):
+    """Shared table, lanes racing on common states.  With lr = 1, gamma = 0 the update writes
+    Q[s][a] = reward, so whatever the interleaving every stored value must be EXACTLY one of the
+    float32 rewards the oracle saw for that (state, action); untouched entries stay 0; no row may
+    exist for a state the oracle never visited.  (Both write modes: store and compare-and-swap.)"""
+    B, steps, seed, id0 = 20000, 60, 33, 400
+    env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=1.0, discount_factor=0.0, exploration_rate=1.0,
+                                      capacity_log2=22, seed=seed, env_id0=id0, device=DEV, strict_td=strict)
+    agent.fused_rollout(env, steps)
+    envs = O.envs_init(B, 4, seed, id0)
+    oa = O.Agent(100, 4, 1.0, 0.0, 1.0)
+    shifts = (4 * np.arange(16, dtype=np.uint64))
+    seen = {}
+    for t in range(steps):
+        keys = (envs["board"][:, :16].astype(np.uint64) << shifts).sum(axis=1)
+        si, sf, a, r, d = O.rollout(envs, oa, 1, seed, id0, t, record=True)
+        r32 = r[0].astype(np.float32)
+        for k, act, rew in zip(keys.tolist(), a[0].tolist(), r32.tolist()):
+            seen.setdefault((k, act), set()).add(rew)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16])
+    dk, dq = agent.export_rows()
+    visited = {k for k, _ in seen} | set(((envs["board"][:, :16].astype(np.uint64) << shifts).sum(axis=1)).tolist())
+    shared = sum(1 for v in seen.values() if len(v) > 1)
+    assert shared > 1000                       # the race is real: many (s, a) saw several rewards
+    bad = 0
+    for k, row in zip(dk.tolist(), dq):
+        assert k in visited
+        for act in range(4):
+            vals = seen.get((k, act))
+            if vals is None:
+                bad += row[act] != 0.0
+            else:
+                bad += float(row[act]) not in vals
+    assert bad == 0 and len(dk) == len(oa)
