@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-_u8p, _f32p, _f64p = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
+# every pointer argument is a device pointer and travels as an integer (c_void_p)
 _SIGNATURES = {
     "q2048_abi_version": (C.c_int, []),
     "q2048_strerror": (C.c_char_p, [C.c_int]),

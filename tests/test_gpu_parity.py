@@ -78,10 +78,8 @@ def _step_draws(pkg, boards, aux, actions, dpos, dval):
     n = len(boards)
     tb, ta = t8(boards), torch.from_numpy(aux.view(np.uint8).reshape(n, 16).copy()).to(DEV)
     act = t8(actions)
-    dp = torch.from_numpy(dpos.astype(np.int64)).to(DEV).to(torch.int64)
     dp32 = torch.from_numpy(np.ascontiguousarray(dpos, dtype=np.uint32).view(np.int32)).to(DEV)
     dv32 = torch.from_numpy(np.ascontiguousarray(dval, dtype=np.uint32).view(np.int32)).to(DEV)
-    del dp
     r = torch.empty(n, dtype=torch.float32, device=DEV)
     d = torch.empty(n, dtype=torch.uint8, device=DEV)
     m = torch.empty(n, dtype=torch.uint8, device=DEV)

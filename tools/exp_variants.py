@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
 
-def run(B, S, steps, warm, eps, td_store, cap_log2, independent=False):
+def run(B, S, steps, warm, eps, td_store, cap_log2, independent=False):  # td_store=False -> CAS TD
     env = pkg.BatchedGame2048Env(B, seed=0, device="cuda:0")
     agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99, exploration_rate=eps,
                                       capacity_log2=cap_log2, device="cuda:0", strict_td=not td_store,
