@@ -1,0 +1,63 @@
+/* examples/rollout_host.c -- the C ABI of include/q2048.h driven from plain C: no Python, no
+ * torch.  Build:  gcc -std=c11 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude
+ *   examples/rollout_host.c -L2048_q-learning_amd/csrc -lq2048_hip -L/opt/rocm/lib -lamdhip64  It runs the fused loop of Agent/main.py:91-101 for B envs and prints the
+ * statistics vector, which tests/test_gpu_parity.py compares with the Python host's.
+ *
+ *   usage: rollout_host <boards> <steps> <seed> <cap_log2> <eps>
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "q2048.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  fprintf(stderr, "HIP error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); return 2; } } while (0)
+#define CHECK_Q(x) do { int e_ = (x); if (e_ != Q2048_OK) { \
+  fprintf(stderr, "q2048 error: %s\n", q2048_strerror(e_)); return 3; } } while (0)
+
+int main(int argc, char **argv) {
+  const int64_t B = argc > 1 ? atoll(argv[1]) : 4096;
+  const int64_t steps = argc > 2 ? atoll(argv[2]) : 64;
+  const uint64_t seed = argc > 3 ? strtoull(argv[3], NULL, 10) : 0;
+  const int cap_log2 = argc > 4 ? atoi(argv[4]) : 22;
+  const double eps = argc > 5 ? atof(argv[5]) : 0.95;
+
+  uint8_t *boards; q2048_aux *aux; q2048_slot *table; int64_t *stats_i; double *stats_f; uint32_t *status;
+  CHECK_HIP(hipMalloc((void **)&boards, (size_t)B * 16));
+  CHECK_HIP(hipMalloc((void **)&aux, (size_t)B * sizeof(q2048_aux)));
+  CHECK_HIP(hipMalloc((void **)&table, sizeof(q2048_slot) << cap_log2));
+  CHECK_HIP(hipMalloc((void **)&stats_i, sizeof(int64_t) * Q2048_NSTAT_I));
+  CHECK_HIP(hipMalloc((void **)&stats_f, sizeof(double) * Q2048_NSTAT_F));
+  CHECK_HIP(hipMalloc((void **)&status, sizeof(uint32_t)));
+  CHECK_HIP(hipMemset(table, 0, sizeof(q2048_slot) << cap_log2));   /* zero = empty table */
+  CHECK_HIP(hipMemset(stats_i, 0, sizeof(int64_t) * Q2048_NSTAT_I));
+  CHECK_HIP(hipMemset(stats_f, 0, sizeof(double) * Q2048_NSTAT_F));
+  CHECK_HIP(hipMemset(status, 0, sizeof(uint32_t)));
+
+  CHECK_Q(q2048_env_init(boards, aux, B, 4, seed, 0, NULL));                    /* Game2048_env() x B */
+  CHECK_Q(q2048_fused_rollout(boards, aux, table, cap_log2, B, 4, steps, eps, 0.1, 0.99, seed, 0, 0, 0,
+                              stats_i, stats_f, status, NULL));
+  CHECK_HIP(hipDeviceSynchronize());
+
+  int64_t si[Q2048_NSTAT_I]; double sf[Q2048_NSTAT_F]; uint32_t st; int64_t rows = 0, *d_rows;
+  CHECK_HIP(hipMemcpy(si, stats_i, sizeof si, hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(sf, stats_f, sizeof sf, hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(&st, status, sizeof st, hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMalloc((void **)&d_rows, sizeof(int64_t)));
+  CHECK_HIP(hipMemset(d_rows, 0, sizeof(int64_t)));
+  CHECK_Q(q2048_table_count(table, cap_log2, d_rows, NULL));                    /* len(q_table) */
+  CHECK_HIP(hipMemcpy(&rows, d_rows, sizeof rows, hipMemcpyDeviceToHost));
+  uint8_t first[16];
+  CHECK_HIP(hipMemcpy(first, boards, 16, hipMemcpyDeviceToHost));
+
+  printf("{\"steps\": %lld, \"episodes\": %lld, \"valid_moves\": %lld, \"score_sum\": %lld, "
+         "\"inserts\": %lld, \"drops\": %lld, \"explored\": %lld, \"rows\": %lld, \"status\": %u, "
+         "\"return_sum\": %.17g, \"board0\": [", (long long)si[Q2048_ST_STEPS],
+         (long long)si[Q2048_ST_EPISODES], (long long)si[Q2048_ST_VALID], (long long)si[Q2048_ST_SCORE],
+         (long long)si[Q2048_ST_INSERTS], (long long)si[Q2048_ST_DROPS], (long long)si[Q2048_ST_EXPLORE],
+         (long long)rows, st, sf[Q2048_SF_RETURN]);
+  for (int c = 0; c < 16; ++c) printf("%d%s", first[c], c < 15 ? ", " : "]}\n");
+  return 0;
+}

@@ -963,3 +963,34 @@ def test_shared_table_writes_are_legitimate_values(pkg, O, strict):
             else:
                 bad += float(row[act]) not in vals
     assert bad == 0 and len(dk) == len(oa)
+
+
+def test_c_host_program_drives_the_abi(pkg, tmp_path):
+    """The boundary is a plain C ABI: examples/rollout_host.c (hipMalloc + q2048_* calls, no
+    Python, no torch) must reproduce the Python host's run."""
+    import shutil
+    import subprocess
+    from conftest import REPO
+    gcc, rocm = shutil.which("gcc"), os.environ.get("ROCM_PATH", "/opt/rocm")
+    if gcc is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("gcc or the HIP runtime headers are not available")
+    exe = str(tmp_path / "rollout_host")
+    libdir = os.path.dirname(pkg._native.LIB_PATH)
+    subprocess.run([gcc, "-std=c11", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"),
+                    "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "rollout_host.c"),
+                    "-o", exe, "-L", libdir, "-lq2048_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+                    f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}"], check=True)
+    B, steps, seed, cap, eps = 5000, 70, 17, 21, 1.0
+    out = subprocess.run([exe, str(B), str(steps), str(seed), str(cap), str(eps)], check=True,
+                         capture_output=True, text=True).stdout
+    got = json.loads(out.strip().splitlines()[-1])
+    env = pkg.BatchedGame2048Env(B, seed=seed, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.99, exploration_rate=eps,
+                                      capacity_log2=cap, seed=seed, device=DEV)
+    agent.fused_rollout(env, steps)
+    st = agent.stats()
+    for k in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "drops", "explored"):
+        assert got[k] == st[k], k
+    assert got["rows"] == agent.table_size() and got["status"] == 0
+    assert got["board0"] == env.boards[0].cpu().tolist()
+    assert np.isclose(got["return_sum"], st["return_sum"], rtol=1e-9)
