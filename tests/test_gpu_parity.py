@@ -626,14 +626,16 @@ def test_5x5_shared_table_pure_exploration(pkg, O):
 # ---------------------------------------------------------------------------------------------
 # full size, table limits, checkpoint
 # ---------------------------------------------------------------------------------------------
-def test_full_size_1m_boards_properties(pkg, O):
-    """BASELINE configs[2] size (1,048,576 boards, shared hash table).  eps = 1 makes every board
-    trajectory a pure function of (seed, global env id, step), so sampled lanes are checked
-    bit-exactly against the oracle and the whole batch through size-independent invariants."""
-    B, seed, id0, launches, S = 1 << 20, 2024, 7, 3, 16
+@pytest.mark.parametrize("B,launches,S,cap", [(1 << 20, 3, 16, 27), (1 << 23, 2, 8, 28)])
+def test_full_size_1m_boards_properties(pkg, O, B, launches, S, cap):
+    """BASELINE configs[2] size (1,048,576 boards, shared hash table) and the whole configs[3]
+    batch (8,388,608 boards) on one GPU.  eps = 1 makes every board trajectory a pure function of
+    (seed, global env id, step), so sampled lanes are checked bit-exactly against the oracle and
+    the whole batch through size-independent invariants."""
+    seed, id0 = 2024, 7
     env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
     agent = pkg.BatchedQLearningAgent(1000, exploration_rate=1.0, discount_factor=0.99,
-                                      capacity_log2=27, seed=seed, env_id0=id0, device=DEV)
+                                      capacity_log2=cap, seed=seed, env_id0=id0, device=DEV)
     for _ in range(launches):
         agent.fused_rollout(env, S)
     steps = launches * S
@@ -656,9 +658,12 @@ def test_full_size_1m_boards_properties(pkg, O):
     assert boards.max() <= 15 and (boards > 0).sum(axis=1).min() >= 2        # legal boards only
     assert sum(st["max_tile_hist"].values()) == st["episodes"]
     # determinism: a second run of the same job gives the same boards and statistics
+    del agent
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
     env2 = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
     agent2 = pkg.BatchedQLearningAgent(1000, exploration_rate=1.0, discount_factor=0.99,
-                                       capacity_log2=27, seed=seed, env_id0=id0, device=DEV)
+                                       capacity_log2=cap, seed=seed, env_id0=id0, device=DEV)
     agent2.fused_rollout(env2, steps)            # one launch instead of three
     assert torch.equal(env.boards, env2.boards) and torch.equal(env.aux, env2.aux)
     st2 = agent2.stats()
