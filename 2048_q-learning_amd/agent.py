@@ -214,6 +214,38 @@ class BatchedQLearningAgent:
         env.ctr += int(steps)
         self.ctr += int(steps)
 
+    def deterministic_rollout(self, env: BatchedGame2048Env, steps: int) -> None:
+        """Reproducible shared-table training, one step per iteration: every env acts on the
+        table as it is at the start of the step, then the updates are grouped by (state, action)
+        and applied in env order.  The result does not depend on how lanes are scheduled and
+        equals the reference agent fed the same transitions in env order (parity at any B);
+        it is several launches and two sorts per step, so use `fused_rollout` for speed."""
+        if env.device != self.device or env.board_size != self.board_size:
+            raise ValueError("env and agent do not match")
+        if (env.seed, env.env_id0, env.ctr) != (self.seed, self.env_id0, self.ctr):
+            raise ValueError("env and agent must share seed, env_id0 and step counter")
+        B, words = env.num_envs, (1 if self.board_size == 4 else 2)
+        keys = torch.empty((B, words), dtype=torch.int64, device=self.device)
+        acts = torch.empty(B, dtype=torch.uint8, device=self.device)
+        target = torch.empty(B, dtype=torch.float64, device=self.device)
+        L, stream = N.lib(), _stream(self.device)
+        for _ in range(int(steps)):
+            N.check(L.q2048_det_phase1(
+                _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, B,
+                self.board_size, float(self.epsilon), float(self.gamma), self.seed, self.env_id0,
+                self.ctr & 0xFFFFFFFF, self.flags, _ptr(keys), _ptr(acts), _ptr(target),
+                _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status), stream), "det_phase1")
+            # stable sorts, least significant criterion first: env order survives inside a group
+            order = torch.argsort(acts, stable=True)
+            for w in reversed(range(words)):
+                order = order[torch.argsort(keys[order, w], stable=True)]
+            ks, as_, ts = keys[order].contiguous(), acts[order].contiguous(), target[order].contiguous()
+            N.check(L.q2048_det_apply(_ptr(self.table), self.capacity_log2, _ptr(ks), _ptr(as_),
+                                      _ptr(ts), B, words, float(self.lr), _ptr(self.status), stream),
+                    "det_apply")
+            env.ctr += 1
+            self.ctr += 1
+
     # -- statistics / table access ---------------------------------------------------------
     def stats(self, reset: bool = False) -> dict:
         """Synchronising host copy of the device statistics."""

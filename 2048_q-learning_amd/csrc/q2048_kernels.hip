@@ -657,6 +657,94 @@ __global__ __launch_bounds__(kBlock) void k_fused_rollout(
 }
 
 // ---------------------------------------------------------------------------------------------
+// deterministic mode: phase 1 (act on the step-start table, emit key / action / target) and
+// phase 2 (apply the updates grouped by (key, action), env order inside a group)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void emit_key(u64* out, int64_t i, const Geo<4>::Key& k) { out[i] = k.k0; }
+__device__ __forceinline__ void emit_key(u64* out, int64_t i, const Geo<5>::Key& k) {
+  out[2 * i] = k.k0; out[2 * i + 1] = k.k1;
+}
+
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_det_phase1(
+    uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
+    uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* keys_out, uint8_t* actions_out,
+    double* target_out, int64_t* stats_i, double* stats_f, uint32_t* status) {
+  __shared__ BlockStats bs;
+  __shared__ Stage<N> st;
+  stats_clear(bs);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  auto b = load_board(boards, i, B, st);
+  if (i < B) {
+    const uint64_t id = env_id0 + (uint64_t)i;
+    const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
+    Aux a = ld_aux(aux, i);
+    const auto key_s = state_key(b, salt, status);
+    Row q, qn;
+    bool ins_s = false, ins_n = false, dropped = false;
+    int64_t slot_s = probe_find(table, mask, key_s, q, ins_s);
+    if (slot_s < 0 && slot_s != kNoSlot) slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
+    if (slot_s < 0) { dropped = true; atomicOr(status, Q2048_STATUS_TABLE_FULL); }
+    const Draws x = draws(seed, id, ctr, kStreamStep);
+    bool explored;
+    const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);     // main.py:92
+    const StepOut o = env_step(b, a, act, x.x2, x.x3);                                  // :93
+    const auto key_n = state_key(b, salt, status);
+    const int64_t slot_n = probe_find(table, mask, key_n, qn, ins_n);                   // :41
+    if (slot_n < 0 && slot_n != kNoSlot) probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
+    emit_key(keys_out, i, key_s);
+    actions_out[i] = (uint8_t)(dropped ? 0xFF : act);      // 0xFF: no row, phase 2 skips it
+    target_out[i] = (double)o.reward +
+                    (gamma * (double)max4(qn.q0, qn.q1, qn.q2, qn.q3) * (o.done ? 0.0 : 1.0));  // :42
+    if (o.done) {
+      episode_stats(bs, a, o.max_log2);
+      begin_episode(b, a, seed, id);
+    }
+    st_aux(aux, i, a);
+    const uint32_t n_valid = wave_count(o.valid != 0), n_explore = wave_count(explored),
+                   n_done = wave_count(o.done != 0), n_ins = wave_count(ins_s) + wave_count(ins_n),
+                   n_drop = wave_count(dropped), n_active = wave_count(true);
+    atomicAdd(&bs.f[Q2048_SF_REWARD], (double)o.reward);
+    if (wave_leader()) {
+      atomicAdd(&bs.i[Q2048_ST_STEPS], (u64)n_active);
+      atomicAdd(&bs.i[Q2048_ST_VALID], (u64)n_valid);
+      atomicAdd(&bs.i[Q2048_ST_EXPLORE], (u64)n_explore);
+      atomicAdd(&bs.i[Q2048_ST_EPISODES], (u64)n_done);
+      atomicAdd(&bs.i[Q2048_ST_INSERTS], (u64)n_ins);
+      atomicAdd(&bs.i[Q2048_ST_DROPS], (u64)n_drop);
+    }
+  }
+  store_board(boards, i, B, b, st);
+  stats_flush(bs, stats_i, stats_f);
+}
+
+template <int WORDS>
+__global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, u64 mask, const u64* keys,
+                                                      const uint8_t* actions, const double* target,
+                                                      int64_t B, double lr, uint32_t* status) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  typename Geo<WORDS == 1 ? 4 : 5>::Key key;
+  key.k0 = keys[i * WORDS];
+  if constexpr (WORDS == 2) key.k1 = keys[i * 2 + 1];
+  const uint32_t act = actions[i];
+  auto same_group = [&](int64_t j) {
+    bool eq = keys[j * WORDS] == key.k0 && actions[j] == act;
+    if constexpr (WORDS == 2) eq = eq && keys[j * 2 + 1] == key.k1;
+    return eq;
+  };
+  if (act > 3u || (i > 0 && same_group(i - 1))) return;   // not the head of a (key, action) group
+  Row r;
+  bool made;
+  const int64_t slot = probe_find(table, mask, key, r, made);
+  if (slot < 0) { atomicOr(status, Q2048_STATUS_TABLE_FULL); return; }
+  float q = row_get(r, (int)act);
+  for (int64_t j = i; j < B && same_group(j); ++j)          // Agent/main.py:43, in env order
+    q = (float)((double)q + lr * (target[j] - (double)q));
+  table[slot].q[act] = q;
+}
+
+// ---------------------------------------------------------------------------------------------
 // row-tuple linear Q (BASELINE configs[1]), 4x4 only.  W = float[4][65536][4] (4 MiB: lives in
 // L2 / Infinity Cache).  Reads are agent-scope loads of whole 16-byte entries.  A write stores
 // old + d with the value the lane gathered (last writer wins): hot row entries are shared by
@@ -992,6 +1080,42 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
   Q2048_LAUNCH(k_fused_rollout, n, B, stream, boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B,
                (int)steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status, log,
                log_capacity, reinterpret_cast<u64*>(log_count));
+  return launch_status();
+}
+
+int q2048_det_phase1(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2, int64_t B, int n,
+                     double eps, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr,
+                     uint32_t flags, uint64_t* keys_out, uint8_t* actions_out, double* target_out,
+                     int64_t* stats_i, double* stats_f, uint32_t* status, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (int e = check_table(table, cap_log2)) return e;
+  if (!boards || !aux || !keys_out || !actions_out || !target_out || !status) return Q2048_ERR_NULL;
+  if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
+  if (!(eps >= 0.0 && eps <= 1.0) || !(gamma == gamma)) return Q2048_ERR_RANGE;
+  if (B == 0) return Q2048_OK;
+  Q2048_LAUNCH(k_det_phase1, n, B, stream, boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B, eps,
+               gamma, seed, env_id0, ctr, flags, reinterpret_cast<u64*>(keys_out), actions_out,
+               target_out, stats_i, stats_f, status);
+  return launch_status();
+}
+
+int q2048_det_apply(q2048_slot* table, int cap_log2, const uint64_t* keys_sorted,
+                    const uint8_t* actions_sorted, const double* target_sorted, int64_t B,
+                    int key_words, double lr, uint32_t* status, void* stream) {
+  if (int e = check_table(table, cap_log2)) return e;
+  if (!keys_sorted || !actions_sorted || !target_sorted || !status) return Q2048_ERR_NULL;
+  if (B < 0 || (key_words != 1 && key_words != 2)) return Q2048_ERR_SIZE;
+  if (!(lr == lr)) return Q2048_ERR_RANGE;
+  if (B == 0) return Q2048_OK;
+  const u64 mask = (1ull << cap_log2) - 1ull;
+  if (key_words == 1)
+    hipLaunchKernelGGL(k_det_apply<1>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
+                       mask, reinterpret_cast<const u64*>(keys_sorted), actions_sorted, target_sorted, B,
+                       lr, status);
+  else
+    hipLaunchKernelGGL(k_det_apply<2>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
+                       mask, reinterpret_cast<const u64*>(keys_sorted), actions_sorted, target_sorted, B,
+                       lr, status);
   return launch_status();
 }
 

@@ -103,6 +103,8 @@ def lib() -> C.CDLL:
         "orc_envs_init": (None, [vp, C.c_int64, C.c_int, C.c_uint64, C.c_uint64]),
         "orc_rollout": (None, [vp, C.c_int64, vp, C.c_int64, C.c_uint64, C.c_uint64,
                                C.c_uint32, u8p, i64p, f64p, u8p, f64p, u8p]),
+        "orc_rollout_sync": (None, [vp, C.c_int64, vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                    i64p, f64p]),
         "orc_rollout_mt": (None, [vp, C.c_int64, C.POINTER(vp), C.c_int, C.c_int64,
                                   C.c_uint64, C.c_uint64, C.c_uint32, i64p, f64p]),
         "orc_rt_new": (vp, []),
@@ -337,6 +339,16 @@ def rollout(envs: np.ndarray, agent: Agent | None, steps: int, seed: int = 0,
                       _ptr(rew, C.c_double), _ptr(dn, C.c_uint8))
     if record:
         return si, sf, acts, rew, dn
+    return si, sf
+
+
+def rollout_sync(envs: np.ndarray, agent: Agent, steps: int, seed: int = 0, env_id0: int = 0,
+                 ctr0: int = 0):
+    """The deterministic two-phase batched semantic (see orc_rollout_sync)."""
+    si = np.zeros(ST_NI, dtype=np.int64)
+    sf = np.zeros(SF_NF, dtype=np.float64)
+    lib().orc_rollout_sync(envs.ctypes.data, len(envs), agent._h, steps, seed, env_id0,
+                           ctr0 & 0xFFFFFFFF, _ptr(si, C.c_int64), _ptr(sf, C.c_double))
     return si, sf
 
 

@@ -495,6 +495,61 @@ void orc_rollout(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t steps,
   }
 }
 
+void orc_rollout_sync(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t steps,
+                      uint64_t seed, uint64_t env_id0, uint32_t ctr0, int64_t *stats_i,
+                      double *stats_f) {
+  uint8_t *s_all = (uint8_t *)malloc((size_t)B * ORC_MAXCELLS);
+  int *act = (int *)malloc((size_t)B * sizeof(int));
+  double *target = (double *)malloc((size_t)B * sizeof(double));
+  for (int64_t t = 0; t < steps; ++t) {
+    for (int64_t i = 0; i < B; ++i) {                      /* phase 1: no table writes */
+      orc_env_t *e = &envs[i];
+      const uint64_t id = env_id0 + (uint64_t)i;
+      uint32_t x[4];
+      orc_draws(seed, id, ctr0 + (uint32_t)t, ORC_STREAM_STEP, x);
+      uint8_t *s = s_all + i * ORC_MAXCELLS;
+      memcpy(s, e->board, ORC_MAXCELLS);
+      int explored = 0;
+      act[i] = orc_agent_choose(agent, s, x[0], x[1], &explored);            /* main.py:92 */
+      double r; int done, mx;
+      const int valid = orc_env_step(e, act[i], x[2], x[3], &r, &done, &mx);   /* :93 */
+      uint8_t k2[ORC_MAXCELLS];
+      orc_key_of(agent, e->board, k2);
+      const orc_row_t *rn = orc_qtable_get(agent->q, k2, NULL);                /* :41 */
+      const double qn = rn->q[orc_argmax4(rn->q, agent->action_space)];
+      const double rf = (double)(float)r;  /* the device hands rewards over as float32 */
+      target[i] = rf + (agent->gamma * qn * (double)(1 - (done ? 1 : 0)));     /* :42 */
+      e->episode_return += rf;
+      if (stats_i) {
+        stats_i[ORC_ST_STEPS] += 1; stats_i[ORC_ST_VALID] += (valid > 0);
+        stats_i[ORC_ST_EXPLORE] += explored;
+      }
+      if (stats_f) stats_f[ORC_SF_REWARD] += rf;
+      if (done) {
+        if (stats_i) {
+          stats_i[ORC_ST_EPISODES] += 1; stats_i[ORC_ST_SCORE] += e->score;
+          stats_i[ORC_ST_HIST0 + (mx > 23 ? 23 : mx)] += 1;
+        }
+        if (stats_f) {
+          stats_f[ORC_SF_RETURN] += e->episode_return;
+          stats_f[ORC_SF_RETURN_SQ] += e->episode_return * e->episode_return;
+        }
+        uint32_t d[4];
+        e->episode += 1;
+        orc_draws(seed, id, e->episode, ORC_STREAM_RESET, d);
+        orc_env_reset(e, d);
+      }
+    }
+    for (int64_t i = 0; i < B; ++i) {                      /* phase 2: updates in env order */
+      uint8_t k1[ORC_MAXCELLS];
+      orc_key_of(agent, s_all + i * ORC_MAXCELLS, k1);
+      orc_row_t *rs = orc_qtable_get(agent->q, k1, NULL);
+      rs->q[act[i]] += agent->lr * (target[i] - rs->q[act[i]]);               /* :43 */
+    }
+  }
+  free(s_all); free(act); free(target);
+}
+
 typedef struct {
   orc_env_t *envs; int64_t B; orc_agent_t *agent; int64_t steps;
   uint64_t seed, env_id0; uint32_t ctr0;

@@ -999,3 +999,41 @@ def test_c_host_program_drives_the_abi(pkg, tmp_path):
     assert got["rows"] == agent.table_size() and got["status"] == 0
     assert got["board0"] == env.boards[0].cpu().tolist()
     assert np.isclose(got["return_sum"], st["return_sum"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("n,B,steps", [(4, 3000, 80), (5, 1500, 60)])
+def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, n, B, steps):
+    """Shared table, lanes meeting on common states, epsilon < 1 (actions depend on Q): the
+    deterministic mode equals the oracle's two-phase semantic -- boards bit-exact, the WHOLE
+    Q-table within tolerance -- and two runs give bit-identical tables."""
+    seed, id0, eps, lr, gamma = 41, 10, 0.2, 0.1, 0.95
+    cells = n * n
+
+    def run():
+        env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+        agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                          capacity_log2=20, seed=seed, env_id0=id0, device=DEV, board_size=n)
+        agent.deterministic_rollout(env, steps)
+        return env, agent
+
+    env, agent = run()
+    envs = O.envs_init(B, n, seed, id0)
+    oa = O.Agent(100, 4, lr, gamma, eps, n=n)
+    si, sf = O.rollout_sync(envs, oa, steps, seed, id0, 0)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :cells])
+    assert_aux(env.aux_fields(), envs, "deterministic")
+    keys, vals = oa.dump()
+    got = agent.q_values(t8(keys)).cpu().numpy()
+    assert np.allclose(got, vals, rtol=1e-5, atol=1e-6)
+    shared = int((np.abs(vals) > 0).sum(axis=1).max())
+    st = agent.stats()
+    assert st["steps"] == B * steps and st["episodes"] == si[O.ST_EPISODES] and st["explored"] == si[O.ST_EXPLORE]
+    assert st["inserts"] == agent.table_size() == len(oa) and st["drops"] == 0 and shared >= 2
+    assert len(oa) < 0.9 * B * steps          # lanes really do share states
+    env2, agent2 = run()
+    assert torch.equal(env.boards, env2.boards)
+    k1, q1 = agent.export_rows(); k2, q2 = agent2.export_rows()
+    k1 = k1.reshape(len(q1), -1); k2 = k2.reshape(len(q2), -1)
+    o1 = np.lexsort(k1.T[::-1]); o2 = np.lexsort(k2.T[::-1])
+    assert np.array_equal(k1[o1], k2[o2]) and np.array_equal(q1[o1], q2[o2])      # bit-identical
+    assert agent.check_status() == 0
