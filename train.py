@@ -45,6 +45,10 @@ def parse_args(argv=None):
     p.add_argument("--steps-per-launch", type=int, default=64)
     p.add_argument("--capacity-log2", type=int, default=0, help="Q-table slots = 2^n (0 = auto)")
     p.add_argument("--strict-td", action="store_true", help="compare-and-swap TD writes")
+    p.add_argument("--deterministic", action="store_true",
+                   help="batched mode: reproducible two-phase steps (slower; see deterministic_rollout)")
+    p.add_argument("--agent", choices=["hash", "row-tuple"], default="hash",
+                   help="hash = the reference's whole-board Q-table; row-tuple = BASELINE configs[1]")
     p.add_argument("--log", default="debug_log.csv", help="CSV log path (Agent/main.py:71)")
     p.add_argument("--report-every", type=int, default=10, help="launches between CSV rows (batched)")
     p.add_argument("--max-steps", type=int, default=0, help="stop after this many env steps per env (0 = off)")
@@ -109,16 +113,26 @@ def train_batched(args, pkg):
     B = shard.num_envs
     # ~220 steps per episode, most of them reach a new state: size for the whole run (load <= 0.5),
     # capped at 2^32 slots = 128 GiB
-    cap = args.capacity_log2 or int(min(32, max(20, np.ceil(np.log2(2.0 * B * 256 * max(args.episodes, 1))))))
+    rows_per_episode = 256 if args.board_size == 4 else 2048     # 5x5 games last several times longer
+    cap = args.capacity_log2 or int(min(32, max(20, np.ceil(np.log2(2.0 * B * rows_per_episode *
+                                                                   max(args.episodes, 1))))))
     env = pkg.BatchedGame2048Env(B, args.board_size, dev, args.seed, shard.env_id0)
-    agent = pkg.BatchedQLearningAgent(args.episodes, 4, args.alpha, args.gamma, args.epsilon,
-                                      args.epsilon_min, cap, dev, args.seed, shard.env_id0,
-                                      strict_td=args.strict_td)
+    if args.agent == "row-tuple":
+        agent = pkg.BatchedRowTupleAgent(args.episodes, 4, args.alpha, args.gamma, args.epsilon,
+                                         args.epsilon_min, dev, args.seed, shard.env_id0)
+    else:
+        agent = pkg.BatchedQLearningAgent(args.episodes, 4, args.alpha, args.gamma, args.epsilon,
+                                          args.epsilon_min, cap, dev, args.seed, shard.env_id0,
+                                          strict_td=args.strict_td, board_size=args.board_size)
+    if args.deterministic and args.agent != "hash":
+        raise SystemExit("--deterministic applies to the hash-table agent")
     if rank == 0:
         with open(args.log, mode="w", newline="") as fh:
             csv.writer(fh).writerow(["Epoch", "Episodes", "Env-Steps", "Epsilon", "Mean-Return",
                                      "Mean-Score", "Max Value", "Table-Rows", "Drops", "Steps/s"])
     ep_log = None
+    if args.episode_log and (args.agent != "hash" or args.deterministic):
+        raise SystemExit("--episode-log needs the fused hash-table path")
     if args.episode_log:
         ep_log = pkg.EpisodeLog(max(4 * B, 1 << 16), device=dev)
         ep_path = args.episode_log if world == 1 else f"{args.episode_log}.rank{rank}"
@@ -129,7 +143,12 @@ def train_batched(args, pkg):
     target = args.episodes * shard.total_envs
     best_tile = 0
     while total_eps < target:
-        agent.fused_rollout(env, args.steps_per_launch, episode_log=ep_log)
+        if args.deterministic:
+            agent.deterministic_rollout(env, args.steps_per_launch)
+        elif ep_log is not None:
+            agent.fused_rollout(env, args.steps_per_launch, episode_log=ep_log)
+        else:
+            agent.fused_rollout(env, args.steps_per_launch)
         launches += 1
         if ep_log is not None:
             with open(ep_path, mode="a", newline="") as fh:      # log_debug_info, Agent/main.py:59-62
