@@ -12,7 +12,8 @@ csrc/libq2048_hip.so (built by __graft_entry__.build()); there is no CPU fallbac
 from . import _native
 from ._native import NativeError, build
 from .agent import (EPISODE_DTYPE, BatchedQLearningAgent, BatchedRowTupleAgent, EpisodeLog,
-                    EpsilonSchedule, QLearningAgent, stats_dict)
+                    EpsilonSchedule, QLearningAgent, auto_capacity_log2, place_table,
+                    stats_dict)
 from .dist import Shard, allreduce_stats, shard_plan, weak_shard
 from .env import (AUX_DTYPE, BatchedGame2048Env, Game2048_env, boards_to_raw, raw_to_boards)
 
@@ -20,5 +21,5 @@ __all__ = [
     "BatchedGame2048Env", "Game2048_env", "BatchedQLearningAgent", "BatchedRowTupleAgent",
     "QLearningAgent",
     "EpsilonSchedule", "EpisodeLog", "EPISODE_DTYPE", "stats_dict", "Shard", "shard_plan", "weak_shard", "allreduce_stats",
-    "boards_to_raw", "raw_to_boards", "AUX_DTYPE", "build", "NativeError",
+    "boards_to_raw", "raw_to_boards", "AUX_DTYPE", "build", "NativeError", "place_table", "auto_capacity_log2",
 ]

@@ -96,6 +96,7 @@ _SIGNATURES = {
                                           C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_void_p]),
+    "q2048_table_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_void_p]),
     "q2048_table_count": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "q2048_det_phase1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                    C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32,

@@ -91,6 +91,75 @@ class _QTableView:
         return self._a.table_size()
 
 
+def _probe_us(table: torch.Tensor, capacity_log2: int, device: torch.device) -> float:
+    """us per 2^20 scattered atomics of q2048_table_probe on `table` (contents unchanged)."""
+    L, stream, lanes, steps = N.lib(), _stream(device), 1 << 20, 16
+    N.check(L.q2048_table_probe(_ptr(table), capacity_log2, lanes, steps, 7, stream), "q2048_table_probe")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for r in range(2):
+        N.check(L.q2048_table_probe(_ptr(table), capacity_log2, lanes, steps, 1000 + r, stream),
+                "q2048_table_probe")
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (2 * steps)
+
+
+def place_table(capacity_log2: int, device: torch.device, placement="auto"):
+    """Allocate the zeroed table where scattered writes run fast.
+
+    Where in device memory a multi-GiB table lies moves the scattered store / atomic rate of the
+    rollout by ~20 % (measured; DESIGN.md 4 "table placement": the EA->DRAM write path stalls more
+    on some placements, loads do not care, the effect belongs to the allocation and does not
+    change over time).  A fresh device hands out slow placements first and the driver offers no
+    control, so the choice is made by measurement.  `placement`:
+      "auto"   tables of 1..32 GiB: best of up to 4 candidates (never more than 3/4 of free
+               memory); smaller ones (cache-resident) and larger ones (they span the memory
+               system and measure fast wherever they lie) as "plain"
+      "plain"  torch.zeros (caching allocator -> hipMalloc): whatever the device yields
+      n (int)  allocate up to n candidates at once, time q2048_table_probe on each (~2 ms,
+               contents untouched), keep the fastest, release the others
+    Returns (table, report)."""
+    shape = (1 << capacity_log2, N.SIZEOF_SLOT)
+    nbytes = N.SIZEOF_SLOT << capacity_log2
+    if placement == "auto":
+        free, _ = torch.cuda.mem_get_info(device)
+        n = min(4, int(0.75 * free) // nbytes) if (1 << 30) <= nbytes <= (32 << 30) else 1
+        placement = "plain" if n < 2 else n
+    if placement == "plain":
+        return torch.zeros(shape, dtype=torch.uint8, device=device), {"mode": "plain"}
+    candidates = int(placement)
+    if candidates < 1:
+        raise ValueError("placement must be 'auto', 'plain' or a candidate count >= 1")
+    tables, times = [], []
+    for _ in range(candidates):
+        try:
+            t = torch.zeros(shape, dtype=torch.uint8, device=device)
+        except torch.OutOfMemoryError:
+            if not tables:
+                raise
+            break
+        tables.append(t)
+        times.append(_probe_us(t, capacity_log2, device))
+    chosen = int(np.argmin(times))
+    table = tables[chosen]
+    del tables, t
+    torch.cuda.empty_cache()                                         # give the other candidates back
+    return table, {"mode": "candidates", "candidates": len(times),
+                   "probe_us": [round(x, 2) for x in times], "chosen": chosen}
+
+
+def auto_capacity_log2(min_rows: int, device, max_log2: int = 33, memory_fraction: float = 0.5) -> int:
+    """Table size for a run that will create up to `min_rows` rows: load factor <= 0.5, and
+    beyond that as much of the device as `memory_fraction` of its free memory allows (a power of
+    two of 32-B slots).  A 64+ GiB table spans the whole memory system -- scattered writes run at
+    the fast rate wherever it lies -- and probes stay one slot long."""
+    need = max(20, int(np.ceil(np.log2(2.0 * max(int(min_rows), 1)))))
+    free, _ = torch.cuda.mem_get_info(torch.device(device))
+    fit = int(np.floor(np.log2(max(memory_fraction * free / N.SIZEOF_SLOT, 2.0))))
+    return min(max(need, min(fit, max_log2)), 40)
+
+
 class BatchedQLearningAgent:
     """QLearningAgent over a batch.  Constructor arguments as Agent/main.py:15; extra keyword
     arguments size and place the device table.
@@ -100,6 +169,8 @@ class BatchedQLearningAgent:
                     (stats['drops'], status TABLE_FULL) -- never an exception.
     independent     every env owns private rows (keys salted with its global id): B independent
                     learners in one table, exactly B reference agents side by side.
+    placement       how the table is allocated (`place_table`): "auto", "plain" or a count of
+                    candidate allocations to probe.  `self.placement` is the report.
     strict_td       update Q[s][a] with a compare-and-swap loop (concurrent updates of one entry
                     serialise) instead of one store (last writer wins).  Same result whenever
                     no two lanes share (s, a); several times slower when many lanes do."""
@@ -107,7 +178,7 @@ class BatchedQLearningAgent:
     def __init__(self, total_epochs, action_space=4, learning_rate=0.1, discount_factor=0.9,
                  exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 24,
                  device="cuda", seed: int = 0, env_id0: int = 0, independent: bool = False,
-                 strict_td: bool = False, board_size: int = 4):
+                 strict_td: bool = False, board_size: int = 4, placement="auto"):
         self.device = _require_gpu(device)
         if action_space != 4:
             raise ValueError("the 2048 action space has 4 actions")
@@ -126,8 +197,7 @@ class BatchedQLearningAgent:
         self.flags = (N.FLAG_INDEPENDENT if independent else 0) | (N.FLAG_TD_CAS if strict_td else 0)
         self.experiment_bits = 0  # unstable tuning bits OR-ed into fused_rollout's flags
         self.ctr = 0  # choose_action calls so far = counter word of the step draws
-        self.table = torch.zeros((1 << self.capacity_log2, N.SIZEOF_SLOT), dtype=torch.uint8,
-                                 device=self.device)
+        self.table, self.placement = place_table(self.capacity_log2, self.device, placement)
         self.stats_i = torch.zeros(N.NSTAT_I, dtype=torch.int64, device=self.device)
         self.stats_f = torch.zeros(N.NSTAT_F, dtype=torch.float64, device=self.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)

@@ -898,6 +898,23 @@ __global__ __launch_bounds__(kBlock) void k_table_import(q2048_slot* table, u64 
   table[slot].q[0] = v.x; table[slot].q[1] = v.y; table[slot].q[2] = v.z; table[slot].q[3] = v.w;
 }
 
+// Placement probe: `steps` scattered device-scope atomic ORs of 0 per lane into key words chosen
+// like the rollout chooses rows -- the table's write-side request pattern with no effect on its
+// contents (x | 0 == x).  The host times it: where in device memory a table lies moves the
+// scattered write / atomic rate by ~20 % (DESIGN.md 4 "table placement"), reads not at all.
+// `zero` is a run-time 0 so that the operation stays an atomic.
+__global__ __launch_bounds__(kBlock) void k_table_probe(q2048_slot* table, u64 mask, int64_t lanes,
+                                                        int steps, uint64_t seed, uint32_t zero) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= lanes) return;
+  u64 x = mix64(seed ^ ((u64)i << 20));
+  for (int t = 0; t < steps; ++t) {
+    x = mix64(x + (u64)t + 1ull);
+    __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(&table[x & mask].key), zero, __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side of the ABI
 // ---------------------------------------------------------------------------------------------
@@ -1207,6 +1224,16 @@ int q2048_table_import(q2048_slot* table, int cap_log2, const uint64_t* keys, co
   else
     hipLaunchKernelGGL(k_table_import<2>, dim3(grid_for(rows)), dim3(kBlock), 0, (hipStream_t)stream,
                        table, mask, reinterpret_cast<const u64*>(keys), q, rows, status);
+  return launch_status();
+}
+
+int q2048_table_probe(q2048_slot* table, int cap_log2, int64_t lanes, int steps, uint64_t seed,
+                      void* stream) {
+  if (int e = check_table(table, cap_log2)) return e;
+  if (lanes < 0 || lanes > ((int64_t)1 << 30) || steps < 0 || steps > (1 << 16)) return Q2048_ERR_SIZE;
+  if (lanes == 0 || steps == 0) return Q2048_OK;
+  hipLaunchKernelGGL(k_table_probe, dim3(grid_for(lanes)), dim3(kBlock), 0, (hipStream_t)stream, table,
+                     (1ull << cap_log2) - 1ull, lanes, steps, seed, 0u);
   return launch_status();
 }
 

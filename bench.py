@@ -58,7 +58,11 @@ def parse_args():
     p.add_argument("--alpha", type=float, default=0.1)
     p.add_argument("--gamma", type=float, default=0.99)
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--cap-log2", type=int, default=0, help="0 = sized from steps (load <= 0.5)")
+    p.add_argument("--cap-log2", type=int, default=0, help="0 = load <= 0.5 and up to half the free device memory")
+    p.add_argument("--placement", default="auto",
+                   type=lambda v: v if v in ("auto", "plain") else int(v),
+                   help="table allocation (agent.place_table): auto | plain (hipMalloc) | "
+                        "N (best of N probed candidates)")
     p.add_argument("--strict-td", action="store_true",
                    help="TD write by compare-and-swap loop (Q2048_FLAG_TD_CAS) instead of one store")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 = skip")
@@ -76,10 +80,11 @@ def pmc_traffic_per_env_step():
         return None
 
 
-def table_capacity_log2(boards: int, total_steps: int) -> int:
-    need = 2 * boards * max(total_steps, 1)      # every step may create a row; keep load <= 0.5
-    cap = max(20, int(np.ceil(np.log2(need))))
-    return min(cap, 32)                          # 2^32 slots x 32 B = 128 GiB of the 288 GB
+def table_capacity_log2(pkg, boards: int, total_steps: int, device) -> int:
+    """Every step may create a row: load <= 0.5 at the end of the run, and beyond that half of
+    the device's free memory (2^32 slots x 32 B = 128 GiB of the 288 GB): a table that large
+    spans the whole memory system, which is where scattered writes run fastest."""
+    return pkg.auto_capacity_log2(boards * max(total_steps, 1), device, max_log2=32)
 
 
 def cpu_baseline(args, seconds: float) -> dict:
@@ -135,7 +140,7 @@ def main():
     B = args.boards_per_gpu
     shard = pkg.weak_shard(B, world, rank)
     S = max(1, min(args.steps_per_launch, args.steps))
-    cap_log2 = args.cap_log2 or table_capacity_log2(B, args.steps + args.warmup)
+    cap_log2 = args.cap_log2 or table_capacity_log2(pkg, B, args.steps + args.warmup, dev)
 
     algo_bytes = ALGO_BYTES_FUSED_4X4 if args.board_size == 4 else ALGO_BYTES_FUSED_5X5
     if args.agent == "row-tuple":
@@ -150,7 +155,8 @@ def main():
         agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
                                           exploration_rate=args.eps, capacity_log2=cap_log2,
                                           seed=args.seed, env_id0=shard.env_id0, device=dev,
-                                          strict_td=args.strict_td, board_size=args.board_size)
+                                          strict_td=args.strict_td, board_size=args.board_size,
+                                          placement=args.placement)
 
     def run(steps):
         launches = 0
@@ -220,6 +226,7 @@ def main():
                    "table_bytes_per_gpu": (1 << cap_log2) * 32, "epsilon": args.eps,
                    "alpha": args.alpha, "gamma": args.gamma, "seed": args.seed,
                    "td_write": "compare-and-swap" if args.strict_td else "store (last writer wins)",
+                   "table_placement": getattr(agent, "placement", None),
                    "parallelism": f"env-batch x{world}, RCCL all-reduce of statistics only"},
         "roofline": roofline,
         "stats": {"episodes": st["episodes"], "mean_return": st["mean_return"],

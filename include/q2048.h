@@ -219,6 +219,14 @@ int q2048_det_apply(q2048_slot *table, int cap_log2, const uint64_t *keys_sorted
                     const uint8_t *actions_sorted, const double *target_sorted, int64_t B,
                     int key_words, double lr, uint32_t *status, void *stream);
 
+/* Placement probe (no reference counterpart): `lanes` lanes each issue `steps` scattered
+ * device-scope atomic ORs of 0 on key words of the table -- the write-side request pattern of
+ * the rollout, leaving every byte of the table as it was, so it may run on a live table.  The
+ * caller times it to choose among candidate allocations (the scattered write / atomic rate
+ * depends on where in device memory a table lies; reads do not). */
+int q2048_table_probe(q2048_slot *table, int cap_log2, int64_t lanes, int steps, uint64_t seed,
+                      void *stream);
+
 /* len(agent.q_table): adds the number of occupied slots to *count (device int64). */
 int q2048_table_count(const q2048_slot *table, int cap_log2, int64_t *count, void *stream);
 

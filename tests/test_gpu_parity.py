@@ -1037,3 +1037,61 @@ def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, n, B, steps
     o1 = np.lexsort(k1.T[::-1]); o2 = np.lexsort(k2.T[::-1])
     assert np.array_equal(k1[o1], k2[o2]) and np.array_equal(q1[o1], q2[o2])      # bit-identical
     assert agent.check_status() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# table placement probe
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [4, 5])
+def test_table_probe_leaves_a_live_table_untouched(pkg, n):
+    """q2048_table_probe issues scattered atomic ORs of 0: every byte of a populated table is
+    as before."""
+    env = pkg.BatchedGame2048Env(4096, board_size=n, seed=3, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.9, exploration_rate=0.5,
+                                      capacity_log2=16, seed=3, device=DEV, board_size=n)
+    assert agent.placement == {"mode": "plain"}          # "auto": small tables are plain
+    agent.fused_rollout(env, 10)
+    assert agent.table_size() > 4096
+    before = agent.table.clone()
+    L = pkg._native.lib()
+    for seed in (0, 1):
+        assert L.q2048_table_probe(agent.table.data_ptr(), 16, 1 << 16, 8, seed, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(agent.table, before)
+    assert L.q2048_table_probe(None, 16, 8, 8, 0, None) == -1
+    assert L.q2048_table_probe(agent.table.data_ptr(), 16, -1, 8, 0, None) == -2
+
+
+def test_table_placements_give_the_same_learner(pkg):
+    """A plain table and the best of three probed candidates: zeroed on arrival, same rollout;
+    auto_capacity_log2 honours the load bound and the memory budget."""
+    ref = None
+    for placement in ("plain", 3):
+        env = pkg.BatchedGame2048Env(8192, seed=5, device=DEV)
+        agent = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.9, exploration_rate=1.0,
+                                          capacity_log2=21, seed=5, device=DEV, placement=placement)
+        assert agent.table.shape == (1 << 21, 32) and int(agent.table.max()) == 0
+        rep = agent.placement
+        if placement == 3:
+            assert rep["mode"] == "candidates" and rep["candidates"] == 3 and len(rep["probe_us"]) == 3
+            assert rep["chosen"] == int(np.argmin(rep["probe_us"])) and min(rep["probe_us"]) > 0
+        agent.fused_rollout(env, 24)           # eps = 1: trajectories do not depend on Q
+        keys, q = agent.export_rows()
+        order = np.argsort(keys)
+        got = (env.boards.cpu().numpy().copy(), keys[order], q[order], agent.stats()["inserts"])
+        if ref is None:
+            ref = got
+        else:
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+            assert got[3] == ref[3]
+            # rows no two lanes shared carry exactly the same values
+            same = np.isclose(got[2], ref[2], rtol=1e-5, atol=1e-6).all(axis=1)
+            assert same.mean() > 0.99
+        del agent, env
+    with pytest.raises(ValueError):
+        pkg.place_table(16, torch.device(DEV), placement=0)
+    free, _ = torch.cuda.mem_get_info(torch.device(DEV))
+    cap = pkg.auto_capacity_log2(1000, DEV)
+    assert 32 << cap <= 0.5 * free < 32 << (cap + 1) or cap == 33
+    assert pkg.auto_capacity_log2(1000, DEV, max_log2=22) == 22
+    assert pkg.auto_capacity_log2(1 << 26, DEV, max_log2=22) == 27       # the load bound wins

@@ -1,0 +1,135 @@
+// Measurement tool (not product code): what do N scattered requests per lane cost on MI355X, and
+// do they overlap with arithmetic?  One lane = one pseudo-board; per step a lane derives a
+// random slot of a 32-B-row table and issues any subset of {16-B probe load, 8-B compare-and-swap
+// on the key word, 4-B store into the row it touched one step earlier}, next to `work` rounds of
+// Philox-like integer arithmetic.  Prints microseconds per 1 Mi-lane step for each combination.
+//
+//   hipcc -O3 --offload-arch=gfx950 -o tools/variants/exp_requests tools/exp_requests.hip
+//   tools/variants/exp_requests [cap_log2=28] [lanes_log2=20] [steps=64] [alloc_log2=cap_log2]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x)                                                                        \
+  do {                                                                               \
+    hipError_t e_ = (x);                                                             \
+    if (e_ != hipSuccess) {                                                          \
+      std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      std::exit(1);                                                                  \
+    }                                                                                \
+  } while (0)
+
+struct Slot { unsigned long long key; float q[4]; unsigned long long pad; };
+static_assert(sizeof(Slot) == 32, "slot");
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) {
+  x ^= x >> 32; x *= 0xd6e8feb86659fd93ull; x ^= x >> 32; x *= 0xd6e8feb86659fd93ull; x ^= x >> 32;
+  return x;
+}
+// `work` units of dependent 32x32->64 multiplies and xors (one unit ~ one Philox4x32-10 call)
+__device__ __forceinline__ uint32_t grind(uint32_t a, uint32_t b, int work) {
+  for (int w = 0; w < work; ++w) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const uint64_t p = (uint64_t)a * 0xD2511F53u, q = (uint64_t)b * 0xCD9E8D57u;
+      a = (uint32_t)(q >> 32) ^ b ^ (uint32_t)(0x9E3779B9u * (uint32_t)r);
+      b = (uint32_t)(p >> 32) ^ a ^ (uint32_t)q ^ (uint32_t)p;
+    }
+  }
+  return a ^ b;
+}
+
+enum { kLoad = 1, kCas = 2, kStore = 4, kCasAlways = 8, kStore16 = 16, kStore32 = 32 };
+
+__global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, int64_t lanes, int steps,
+                                                  int what, int work, uint32_t ctr0, uint32_t* sink) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= lanes) return;
+  uint32_t acc = (uint32_t)i;
+  uint64_t prev = mix((uint64_t)i) & mask;
+  for (int t = 0; t < steps; ++t) {
+    acc = grind(acc, (uint32_t)t + ctr0, work);
+    const uint64_t key = mix(((uint64_t)i << 32) ^ (uint64_t)(ctr0 + (uint32_t)t) ^ ((uint64_t)acc << 13)) | 1ull;
+    const uint64_t at = (key >> 7) & mask;
+    uint64_t seen = 0ull;
+    if (what & kLoad) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 v;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(&table[at]) : "memory");
+      seen = (uint64_t)v.x | ((uint64_t)v.y << 32);
+      acc ^= v.z;
+    }
+    if ((what & kCasAlways) || ((what & kCas) && seen == 0ull)) {
+      const uint64_t r = atomicCAS(&table[at].key, 0ull, key);
+      acc ^= (uint32_t)r;                       // the result is consumed (like the real claim)
+    }
+    if (what & kStore) *reinterpret_cast<uint32_t*>(&table[prev].q[key & 3ull]) = acc;
+    if (what & (kStore16 | kStore32)) {        // whole 16-B half / whole 32-B row (no partial sector)
+      uint4* row = reinterpret_cast<uint4*>(&table[prev]);
+      row[0] = make_uint4((uint32_t)key | 1u, (uint32_t)(key >> 32), acc, acc);
+      if (what & kStore32) row[1] = make_uint4(acc, acc, 0u, 0u);
+    }
+    prev = at;
+  }
+  if (acc == 0x12345u) *sink = acc;
+}
+
+int main(int argc, char** argv) {
+  const int cap_log2 = argc > 1 ? std::atoi(argv[1]) : 28;
+  const int lanes_log2 = argc > 2 ? std::atoi(argv[2]) : 20;
+  const int steps = argc > 3 ? std::atoi(argv[3]) : 64;
+  const int alloc_log2 = argc > 4 ? std::atoi(argv[4]) : cap_log2;   // allocate more than is used
+  if (cap_log2 < 10 || cap_log2 > 32 || alloc_log2 < cap_log2 || alloc_log2 > 32 || lanes_log2 < 6 || lanes_log2 > 24 || steps < 1 || steps > 4096) {
+    std::fprintf(stderr, "bad arguments\n");
+    return 2;
+  }
+  const uint64_t cap = 1ull << cap_log2;
+  const int64_t lanes = (int64_t)1 << lanes_log2;
+  Slot* table;
+  uint32_t* sink;
+  CK(hipMalloc(&table, (1ull << alloc_log2) * sizeof(Slot)));
+  CK(hipMalloc(&sink, 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const unsigned grid = (unsigned)((lanes + 255) / 256);
+  struct { const char* name; int what; } combos[] = {
+      {"none", 0}, {"load", kLoad}, {"store", kStore}, {"cas(always)", kCasAlways},
+      {"load+cas", kLoad | kCas}, {"load+store", kLoad | kStore},
+      {"load+cas+store", kLoad | kCas | kStore}, {"cas(always)+store", kCasAlways | kStore},
+      {"store16", kStore16}, {"store32", kStore32}, {"load+store32", kLoad | kStore32},
+      {"load+cas+store32", kLoad | kCas | kStore32}};
+  std::printf("{\"alloc_log2\": %d, \"cap_log2\": %d, \"lanes\": %lld, \"steps\": %d, \"unit\": \"us per step per 2^20 lanes\", \"rows\": [\n",
+              alloc_log2, cap_log2, (long long)lanes, steps);
+  bool first = true;
+  for (auto& c : combos) {
+    for (int work : {0, 5}) {
+      CK(hipMemsetAsync(table, 0, cap * sizeof(Slot), 0));       // every run starts on an empty table
+      uint32_t ctr = 0;
+      hipLaunchKernelGGL(k_requests, dim3(grid), dim3(256), 0, 0, table, cap - 1, lanes, steps, c.what,
+                         work, ctr, sink);                        // warm-up (fills steps*lanes keys)
+      ctr += (uint32_t)steps;
+      CK(hipEventRecord(e0, 0));
+      const int reps = 3;
+      for (int r = 0; r < reps; ++r) {
+        hipLaunchKernelGGL(k_requests, dim3(grid), dim3(256), 0, 0, table, cap - 1, lanes, steps, c.what,
+                           work, ctr, sink);
+        ctr += (uint32_t)steps;
+      }
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = (double)ms * 1e3 / (reps * steps) * (double)(1 << 20) / (double)lanes;
+      std::printf("%s  {\"requests\": \"%s\", \"work\": %d, \"us\": %.2f}", first ? "" : ",\n", c.name, work, us);
+      first = false;
+      std::fflush(stdout);
+    }
+  }
+  std::printf("\n]}\n");
+  CK(hipFree(table));
+  CK(hipFree(sink));
+  return 0;
+}
