@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
 MODES = {"store_plain": 0, "cas": 1, "store_sc1": 2, "add": 6, "none": 4}
 
-def run(name, bits, B=1 << 20, S=16, steps=128, warm=64, eps=0.95, cap_log2=29, warm_bits=None):
+def run(name, bits, B=1 << 20, S=16, steps=128, warm=64, eps=0.95, cap_log2=32, warm_bits=None):
     env = pkg.BatchedGame2048Env(B, seed=0, device="cuda:0")
     agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99, exploration_rate=eps,
                                       capacity_log2=cap_log2, device="cuda:0")
@@ -34,4 +34,4 @@ if __name__ == "__main__":
     for S in (1, 4, 64, 256):
         run(f"store_plain S={S}", 0, S=S, steps=256 if S >= 64 else 128)
     run("cas S=64", 1 << 8, S=64)
-    run("store_plain B=4M", 0, B=4 << 20, steps=64, cap_log2=30)
+    run("store_plain B=4M", 0, B=4 << 20, steps=64, cap_log2=32)
