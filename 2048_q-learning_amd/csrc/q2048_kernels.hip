@@ -539,8 +539,14 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
 // reference's defaultdict creates them (q_table[next_state] / q_table[state] in
 // update_q_value, Agent/main.py:41-43).
 // ---------------------------------------------------------------------------------------------
+// Waves per SIMD the register allocator must leave room for.  6 (<= 80 VGPRs, 5 dwords of
+// scratch) measures +2 % over the unconstrained 88 VGPRs / 5 waves; 7 and 8 spill more than the
+// extra waves hide (-9 %, -17 %).
+#ifndef Q2048_FUSED_MIN_WAVES
+#define Q2048_FUSED_MIN_WAVES 6
+#endif
 template <int N>
-__global__ __launch_bounds__(kBlock) void k_fused_rollout(
+__global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
     double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
     int64_t* stats_i, double* stats_f, uint32_t* status, q2048_episode* log, int64_t log_cap,
