@@ -12,6 +12,7 @@
 // statistics go through LDS, and each block ends with one global atomic per statistic.
 // Every kernel is written once over the board geometry (template <int N>, N = 4 or 5).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "q2048.h"
@@ -26,6 +27,7 @@ constexpr int kMaxCas = 4096;    // TD compare-and-swap retries before the addit
 
 static_assert(sizeof(q2048_aux) == 16 && sizeof(q2048_slot) == 32, "ABI layout");
 static_assert(sizeof(q2048_episode) == 48, "ABI layout");
+static_assert(offsetof(q2048_slot, q) == 8 && offsetof(q2048_slot, reserved) == 24, "ABI layout");
 static_assert(sizeof(Aux) == sizeof(q2048_aux), "core/ABI aux mismatch");
 
 using u64 = unsigned long long;
@@ -126,18 +128,13 @@ __device__ __forceinline__ u64 key_home(const Geo<5>::Key& k, u64 mask) {
 // CUs' atomics never refresh); rows are claimed with a device-scope compare-and-swap on the key
 // word.  Keys are written once (0 -> key) and never change, so a stale read can only miss a
 // brand-new row, which reads as the zero row it still is for the reader.  5x5 keys take two
-// words, claimed one after the other without ever waiting (see `confirm`).
+// words, claimed one after the other without ever waiting for another lane (see `confirm`).
 // ---------------------------------------------------------------------------------------------
 struct Row { float q0, q1, q2, q3; };
 
 __device__ __forceinline__ u64 ld_u64(const void* p) {
   return __hip_atomic_load(const_cast<u64*>(reinterpret_cast<const u64*>(p)), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ Row ld_row(const q2048_slot* s) {
-  const u64 a = ld_u64(&s->q[0]), b = ld_u64(&s->q[2]);
-  return Row{bits_f32((uint32_t)a), bits_f32((uint32_t)(a >> 32)), bits_f32((uint32_t)b),
-             bits_f32((uint32_t)(b >> 32))};
 }
 __device__ __forceinline__ float row_get(const Row& r, int a) {
   return a == 0 ? r.q0 : a == 1 ? r.q1 : a == 2 ? r.q2 : r.q3;
@@ -157,9 +154,9 @@ __device__ __forceinline__ bool confirm(q2048_slot*, const Geo<4>::Key&, bool wo
   completed = won;
   return true;
 }
-__device__ __forceinline__ bool confirm(q2048_slot* s, const Geo<5>::Key& key, bool, bool& completed) {
+__device__ __forceinline__ bool confirm(q2048_slot* s, const Geo<5>::Key& key, bool won, bool& completed) {
   completed = false;
-  u64 hi = ld_u64(&s->reserved);
+  u64 hi = won ? 0ull : ld_u64(&s->reserved);  // just claimed: the second word is 0 unless a helper was faster
   if (hi == 0ull) {
     hi = atomicCAS(reinterpret_cast<u64*>(&s->reserved), 0ull, key.k1);
     if (hi == 0ull) { completed = true; return true; }
@@ -172,40 +169,25 @@ __device__ __forceinline__ bool confirm(q2048_slot* s, const Geo<5>::Key& key, b
 // kNoSlot when the probe limit was hit.  `created` is set when this lane completed a half-made
 // 5x5 row on the way (it then owns a fresh zero row); it never is on 4x4.
 constexpr int64_t kNoSlot = INT64_MIN;
-template <class Key>
-__device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask, const Key& key,
-                                              Row& row, bool& created) {
-  u64 i = key_home(key, mask);
-  row = Row{0.f, 0.f, 0.f, 0.f};
-  created = false;
-  for (int p = 0; p < kMaxProbe; ++p) {
-    const u64 k = ld_u64(&table[i].key);
-    if (k == 0ull) return ~(int64_t)i;
-    if (k == key.k0 && confirm(const_cast<q2048_slot*>(&table[i]), key, false, created)) {
-      if (!created) row = ld_row(&table[i]);
-      return (int64_t)i;
-    }
-    i = (i + 1ull) & mask;
-  }
-  return kNoSlot;
+// The cost of the table is the NUMBER of scattered requests a lane issues, whatever line they
+// hit, so the probe reads {key, q0, q1} with ONE
+// 16-byte load and the other half of the slot only on a key match.  The load carries sc1 like
+// the agent-scope 8-byte loads it replaces (bypasses the per-CU L1, keeps the default L2 /
+// Infinity Cache policy: a non-temporal load made the next step's claim of the same line twice
+// as slow).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ld16_agent(const void* p) {  // waited for in place
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
 }
-
-// 4x4 lookup.  The cost of the table is the NUMBER of scattered requests (measured: ~8 us per
-// million loads, ~11 per million stores, ~25 per million atomics, whatever line they hit), so the
-// probe reads {key, q0, q1} with ONE 16-byte load and fetches {q2, q3} only on a hit.  The load
-// carries sc1 like the agent-scope 8-byte loads it replaces (bypasses the per-CU L1, keeps the
-// default L2 / Infinity Cache policy: a non-temporal load made the next step's claim of the same
-// line twice as slow).
 __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
                                               const Geo<4>::Key& key, Row& row, bool& created) {
   u64 i = key_home(key, mask);
   created = false;
   row = Row{0.f, 0.f, 0.f, 0.f};
   for (int p = 0; p < kMaxProbe; ++p) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 v;  // agent-scope (sc1: L1-bypassing, default L2 policy) 16-byte load; waited for in place
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=v"(v) : "v"(&table[i]) : "memory");
+    const u32x4 v = ld16_agent(&table[i]);
     const u64 k = (u64)v.x | ((u64)v.y << 32);
     if (k == key.k0) {
       const u64 hi = ld_u64(&table[i].q[2]);
@@ -213,6 +195,35 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
       return (int64_t)i;
     }
     if (k == 0ull) return ~(int64_t)i;
+    i = (i + 1ull) & mask;
+  }
+  return kNoSlot;
+}
+
+// 5x5: {key, q0, q1} first; on a first-word match {q2, q3, second key word} -- two requests for
+// a hit instead of four (key, second word, two row halves).  A slot whose second word is still 0
+// is completed here exactly as `confirm` does.
+__device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
+                                              const Geo<5>::Key& key, Row& row, bool& created) {
+  u64 i = key_home(key, mask);
+  created = false;
+  row = Row{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < kMaxProbe; ++p) {
+    const u32x4 a = ld16_agent(&table[i]);
+    const u64 k = (u64)a.x | ((u64)a.y << 32);
+    if (k == 0ull) return ~(int64_t)i;
+    if (k == key.k0) {
+      const u32x4 b = ld16_agent(&table[i].q[2]);
+      u64 hi = (u64)b.z | ((u64)b.w << 32);
+      if (hi == 0ull) {
+        hi = atomicCAS(const_cast<u64*>(reinterpret_cast<const u64*>(&table[i].reserved)), 0ull, key.k1);
+        if (hi == 0ull) { created = true; return (int64_t)i; }  // this lane completed it: a zero row
+      }
+      if (hi == key.k1) {
+        row = Row{bits_f32(a.z), bits_f32(a.w), bits_f32(b.x), bits_f32(b.y)};
+        return (int64_t)i;
+      }
+    }
     i = (i + 1ull) & mask;
   }
   return kNoSlot;
@@ -237,34 +248,57 @@ __device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, con
   return kNoSlot;
 }
 
-// A row claim in flight (4x4): the compare-and-swap was issued, its result is consumed one step
-// later, so the round trip hides behind the next step's arithmetic.  5x5 claims synchronously
-// (the second key word has to follow the first at once).
-struct Claim { u64 ret; u64 at; bool active; };
+// A row claim in flight.  The compare-and-swap is issued when the probe finds the state absent
+// and its result is consumed one step later, when s' has become s, so the round trip hides
+// behind the next step's arithmetic.  5x5 keys take two words: the second compare-and-swap is
+// issued as soon as the first has returned (after the env step) and is in flight during the
+// probe of the next state -- two dependent round trips in a row cost 2x the time of the whole
+// rest of the step when they were waited for in place.
+//   stage 0 idle, 1 first key word in flight, 2 second key word in flight (5x5), 3 the slot went
+//   to another key (5x5: found when the first word returned)
+struct Claim { u64 ret; u64 at; int stage; };
 
-__device__ __forceinline__ int64_t claim_issue(q2048_slot* table, u64, int64_t slot,
-                                               const Geo<4>::Key& key, Claim& c, bool&) {
-  c.active = slot < 0 && slot != kNoSlot;
-  if (c.active) {
+__device__ __forceinline__ void claim_issue(q2048_slot* table, int64_t slot, const Geo<4>::Key& key,
+                                            Claim& c) {
+  if (slot < 0 && slot != kNoSlot) {
     c.at = (u64)~slot;
     c.ret = atomicCAS(reinterpret_cast<u64*>(&table[c.at].key), 0ull, key.k0);
+    c.stage = 1;
   }
-  return slot;
 }
-__device__ __forceinline__ int64_t claim_issue(q2048_slot* table, u64 mask, int64_t slot,
-                                               const Geo<5>::Key& key, Claim& c, bool& inserted) {
-  c.active = false;
-  if (slot < 0 && slot != kNoSlot) return probe_insert(table, mask, key, (u64)~slot, inserted);
-  return slot;
+__device__ __forceinline__ void claim_issue(q2048_slot* table, int64_t slot, const Geo<5>::Key& key,
+                                            Claim& c) {
+  claim_issue(table, slot, Geo<4>::Key{key.k0}, c);
 }
-template <class Key>
-__device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, const Key& key, Claim& c,
-                                                 int64_t slot, bool& inserted) {
-  if (!c.active) return slot;
-  c.active = false;
+__device__ __forceinline__ void claim_advance(q2048_slot*, const Geo<4>::Key&, Claim&) {}
+__device__ __forceinline__ void claim_advance(q2048_slot* table, const Geo<5>::Key& key, Claim& c) {
+  if (c.stage != 1) return;
+  if (c.ret == 0ull || c.ret == key.k0) {  // the first word is ours (or equal): settle the second
+    c.ret = atomicCAS(reinterpret_cast<u64*>(&table[c.at].reserved), 0ull, key.k1);
+    c.stage = 2;
+  } else {
+    c.stage = 3;
+  }
+}
+__device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, const Geo<4>::Key& key,
+                                                 Claim& c, int64_t slot, bool& inserted) {
+  if (c.stage == 0) return slot;
+  c.stage = 0;
   if (c.ret == 0ull) { inserted = true; return (int64_t)c.at; }
   if (c.ret == key.k0) return (int64_t)c.at;
   return probe_insert(table, mask, key, c.at + 1ull, inserted);  // another key took the slot
+}
+__device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, const Geo<5>::Key& key,
+                                                 Claim& c, int64_t slot, bool& inserted) {
+  if (c.stage == 0) return slot;
+  claim_advance(table, key, c);            // no-op unless the first word is still the last thing issued
+  const int stage = c.stage;
+  c.stage = 0;
+  if (stage == 2) {                        // the slot belongs to whoever set the second word (`confirm`)
+    if (c.ret == 0ull) { inserted = true; return (int64_t)c.at; }
+    if (c.ret == key.k1) return (int64_t)c.at;
+  }
+  return probe_insert(table, mask, key, c.at + 1ull, inserted);
 }
 
 // update_q_value on one entry (Agent/main.py:43) against its CURRENT value.  `guess` is the
@@ -534,8 +568,8 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
 //
 // Per step and lane the table sees: one probe of the next state (a read), at most one row claim
 // (compare-and-swap on the key word, only for a state reached for the first time) and one
-// 4-byte write of Q[s][a].  On 4x4 the claim of s' is issued as soon as the probe finds it
-// absent and consumed one step later, when s' has become s.  Rows appear exactly when the
+// 4-byte write of Q[s][a].  The claim of s' is issued as soon as the probe finds it absent and
+// consumed one step later, when s' has become s (5x5: first key word, then the second: `Claim`).  Rows appear exactly when the
 // reference's defaultdict creates them (q_table[next_state] / q_table[state] in
 // update_q_value, Agent/main.py:41-43).
 // ---------------------------------------------------------------------------------------------
@@ -567,7 +601,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
     Row q;
     bool made0 = false;
     int64_t slot_s = probe_find(table, mask, key_s, q, made0);
-    Claim claim{0ull, 0ull, false};
+    Claim claim{0ull, 0ull, 0};
     // wave-uniform counters (ballots) and rare per-lane ones
     uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = wave_count(made0), n_drop = 0;
     uint32_t retries = 0;
@@ -582,16 +616,19 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
       const bool same = key_eq(key_n, key_s);
       // the row of s: claimed one step ago (in flight since), or now if s opened the episode/launch
       bool ins_s = false, ins_n = false;
-      slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_s);
-      if (slot_s < 0 && slot_s != kNoSlot && !x_noclaim)
-        slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
+      if constexpr (N == 4) slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_s);
+      else claim_advance(table, key_s, claim);      // second key word: in flight during the probe
       // q_table[next_state] (:41)
       Row qn = q;
-      int64_t slot_n = slot_s;
+      int64_t slot_n = kNoSlot;
       if (!same) {
         if (x_noprobe) { qn = Row{0.f, 0.f, 0.f, 0.f}; slot_n = ~(int64_t)key_home(key_n, mask); }
         else slot_n = probe_find(table, mask, key_n, qn, ins_n);
       }
+      if constexpr (N == 5) slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_s);
+      if (slot_s < 0 && slot_s != kNoSlot && !x_noclaim)   // s opened the episode / launch
+        slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
+      if (same) slot_n = slot_s;
       const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
       float nq = 0.f;
       const bool updated = slot_s >= 0;
@@ -627,11 +664,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
         else slot_s = kNoSlot;      // dropped: do not retry the claim with a stale hint
       } else {
         key_s = key_n; slot_s = slot_n; q = qn;                                        // :100
-        if (!x_noclaim) {
-          bool made = false;
-          slot_s = claim_issue(table, mask, slot_s, key_s, claim, made);
-          ins_n = ins_n || made;
-        }
+        if (!x_noclaim) claim_issue(table, slot_s, key_s, claim);
       }
       n_valid += wave_count(o.valid != 0);
       n_explore += wave_count(explored);
