@@ -1095,3 +1095,29 @@ def test_table_placements_give_the_same_learner(pkg):
     assert 32 << cap <= 0.5 * free < 32 << (cap + 1) or cap == 33
     assert pkg.auto_capacity_log2(1000, DEV, max_log2=22) == 22
     assert pkg.auto_capacity_log2(1 << 26, DEV, max_log2=22) == 27       # the load bound wins
+
+
+def test_device_spanning_table_uses_64_bit_slot_indices(pkg):
+    """The bench's table (auto_capacity_log2: half of the free memory, 2^32 slots on a 288 GB
+    device): rows land above slot 2^31 and above byte offset 2^36, every insert is a row, no drops."""
+    dev = torch.device(DEV)
+    torch.cuda.empty_cache()                                 # tables cached by earlier tests
+    cap = pkg.auto_capacity_log2(1 << 25, dev, max_log2=32)
+    if cap < 32:
+        pytest.skip(f"free device memory only allows 2^{cap} slots")
+    env = pkg.BatchedGame2048Env(1 << 20, seed=11, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.9, exploration_rate=0.9,
+                                      capacity_log2=cap, seed=11, device=DEV)
+    assert agent.placement == {"mode": "plain"}
+    for _ in range(2):
+        agent.fused_rollout(env, 16)
+    st = agent.stats()
+    assert st["drops"] == 0 and agent.check_status() == 0
+    assert agent.table_size() == st["inserts"] > (1 << 22)
+    upper = agent.table[(1 << 31):, :8]                      # key words of the upper half
+    frac_upper = float((upper != 0).any(dim=1).sum()) / st["inserts"]
+    assert 0.45 < frac_upper < 0.55                          # uniformly hashed over all 2^32 slots
+    q = agent.q_values(env.boards[:4096])                    # current states are in the table
+    assert q.shape == (4096, 4) and bool(torch.isfinite(q).all())
+    del agent, env, upper
+    torch.cuda.empty_cache()
