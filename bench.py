@@ -189,6 +189,7 @@ def main():
     kernel_ms_max = pkg.dist.max_over_ranks(kernel_ms, device=dev)
 
     st = agent.stats()                     # all-reduced: whole-job numbers
+    table_rows = agent.table_size() if args.agent == "hash" else None   # this rank's replica, after W + K steps
     status = agent.check_status()
     total_env_steps = shard.total_envs * args.steps
     assert st["steps"] == total_env_steps, (st["steps"], total_env_steps)
@@ -232,6 +233,8 @@ def main():
         "stats": {"episodes": st["episodes"], "mean_return": st["mean_return"],
                   "mean_score": st["mean_score"], "valid_move_frac": st["valid_moves"] / max(st["steps"], 1),
                   "table_inserts": st["inserts"], "drops": st["drops"],
+                  "table_rows_per_gpu": table_rows,
+                  "table_load_factor": None if table_rows is None else table_rows / float(1 << cap_log2),
                   "cas_retries": st["cas_retries"], "status": status,
                   "max_tile_hist": {str(k): v for k, v in st["max_tile_hist"].items()}},
         "kernel_ms_total": kernel_ms_max,
