@@ -785,21 +785,32 @@ __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, u64 mas
 
 // ---------------------------------------------------------------------------------------------
 // row-tuple linear Q (BASELINE configs[1]), 4x4 only.  W = float[4][65536][4] (4 MiB: lives in
-// L2 / Infinity Cache).  Reads are agent-scope loads of whole 16-byte entries.  A write stores
+// L2 / Infinity Cache).  Reads are agent-scope loads of whole 16-byte entries (one request per
+// entry; the fused loop gathers each state once, as s', and carries it into the next step: 4
+// loads + 4 stores per env step instead of 16 + 4).  A write stores
 // old + d with the value the lane gathered (last writer wins): hot row entries are shared by
 // most of the batch, and summing every lane's delta (atomic add) multiplies the step size by the
 // number of concurrent lanes and diverges.  With one lane this is the sequential learner.
 // ---------------------------------------------------------------------------------------------
 struct RtRows { Row e0, e1, e2, e3; };
-__device__ __forceinline__ Row rt_entry(const float* w, uint32_t r, uint32_t idx) {
-  const float* e = w + (((size_t)r * kRtIdx + idx) << 2);
-  const u64 a = ld_u64(e), b = ld_u64(e + 2);
-  return Row{bits_f32((uint32_t)a), bits_f32((uint32_t)(a >> 32)), bits_f32((uint32_t)b),
-             bits_f32((uint32_t)(b >> 32))};
+__device__ __forceinline__ const float* rt_addr(const float* w, uint32_t r, uint32_t idx) {
+  return w + (((size_t)r * kRtIdx + idx) << 2);
 }
+__device__ __forceinline__ Row rt_row(const u32x4& v) {
+  return Row{bits_f32(v.x), bits_f32(v.y), bits_f32(v.z), bits_f32(v.w)};
+}
+// the four entries of a board: four 16-byte agent-scope loads in flight together, one wait
 __device__ __forceinline__ RtRows rt_gather(const float* w, const Board& b) {
-  return RtRows{rt_entry(w, 0, pack_row(b.r0)), rt_entry(w, 1, pack_row(b.r1)),
-                rt_entry(w, 2, pack_row(b.r2)), rt_entry(w, 3, pack_row(b.r3))};
+  u32x4 v0, v1, v2, v3;
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+      "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+      : "v"(rt_addr(w, 0, pack_row(b.r0))), "v"(rt_addr(w, 1, pack_row(b.r1))),
+        "v"(rt_addr(w, 2, pack_row(b.r2))), "v"(rt_addr(w, 3, pack_row(b.r3)))
+      : "memory");
+  return RtRows{rt_row(v0), rt_row(v1), rt_row(v2), rt_row(v3)};
 }
 __device__ __forceinline__ Row rt_q(const RtRows& e) {
   return Row{rt_sum(e.e0.q0, e.e1.q0, e.e2.q0, e.e3.q0), rt_sum(e.e0.q1, e.e1.q1, e.e2.q1, e.e3.q1),
@@ -867,15 +878,16 @@ __global__ __launch_bounds__(kBlock) void k_rt_fused_rollout(
     Aux a = ld_aux(aux, i);
     uint32_t n_valid = 0, n_explore = 0, n_done = 0;
     double reward_sum = 0.0;
+    RtRows es = rt_gather(w, b);   // entries of the current state, carried from step to step
     for (int t = 0; t < steps; ++t) {
       const Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
       const Board s = b;
-      const RtRows es = rt_gather(w, s);
       const Row q = rt_q(es);
       bool explored;
       const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);
       const StepOut o = env_step(b, a, act, x.x2, x.x3);
-      const Row qn = rt_q(rt_gather(w, b));
+      RtRows en = rt_gather(w, b);
+      const Row qn = rt_q(en);
       const float d = rt_delta(row_get(q, act), o.reward, max4(qn.q0, qn.q1, qn.q2, qn.q3),
                                o.done != 0, lr, gamma);
       rt_scatter(w, s, es, act, d);
@@ -886,6 +898,15 @@ __global__ __launch_bounds__(kBlock) void k_rt_fused_rollout(
       if (o.done) {
         episode_stats(bs, a, o.max_log2);
         begin_episode(b, a, seed, id);
+        es = rt_gather(w, b);
+      } else {
+        // s' becomes s: its entries were gathered before the write above, so a row that did not
+        // move (same index in the same position) takes the value just written
+        if (pack_row(b.r0) == pack_row(s.r0)) row_set(en.e0, act, row_get(es.e0, act) + d);
+        if (pack_row(b.r1) == pack_row(s.r1)) row_set(en.e1, act, row_get(es.e1, act) + d);
+        if (pack_row(b.r2) == pack_row(s.r2)) row_set(en.e2, act, row_get(es.e2, act) + d);
+        if (pack_row(b.r3) == pack_row(s.r3)) row_set(en.e3, act, row_get(es.e3, act) + d);
+        es = en;
       }
     }
     store_board(boards, i, B, b, st);

@@ -35,8 +35,9 @@ if REPO not in sys.path:
 
 ALGO_BYTES_FUSED_4X4 = 122  # SURVEY.md section 8(d) / BASELINE.md section 4
 ALGO_BYTES_FUSED_5X5 = 156
-# row-tuple learner: 64 B board+aux stream, 8 gathered 16-B entries, 4 weight writes, 6 B out.  The
-# 4 MiB weight table is cache-resident, so this figure is not HBM traffic.
+# row-tuple learner: 64 B board+aux stream, 8 gathered 16-B entries (Q(s) and Q(s'); the kernel
+# reuses s' as the next s and gathers 4), 4 weight writes, 6 B out.  The 4 MiB weight table is
+# cache-resident, so this figure is not HBM traffic.
 ALGO_BYTES_ROW_TUPLE = 64 + 8 * 16 + 4 * 4 + 6
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
