@@ -830,6 +830,12 @@ def test_episode_log_matches_reference_csv_rows(pkg):
         assert rec["score"] == g["ep_scores"][e]
         assert np.array_equal(np.asarray(rec["q"]), last_rows[e])       # Q-Values = live row of `state`
     assert np.array_equal(env.boards.cpu().numpy(), g["final_boards"])
+    # the run summary in the layout of plots/summary_statistics_cleaned.csv, from the device
+    # records, against the same aggregate of the reference's transcript
+    got_row = pkg.summarize_records("g6", np.array(recs))
+    want_row = pkg.summarize_episodes("g6", g["actions"][ends], g["rewards"][ends], g["maxes"][ends])
+    assert got_row[0] == "g6" and got_row[3:] == want_row[3:]           # Max_Value, Action_0..3
+    assert np.allclose(got_row[1:3], want_row[1:3], rtol=1e-6)          # Avg / Std of float32 rewards
     # the whole Q-table of the run against the reference's dict
     got = agent.q_values(t8(g["q_keys"])).cpu().numpy()
     assert np.allclose(got, g["q_vals"], rtol=1e-5, atol=1e-6) and agent.table_size() == len(g["q_keys"])

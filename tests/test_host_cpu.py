@@ -112,6 +112,46 @@ def test_board_conversions(pkg):
     assert np.array_equal(pkg.raw_to_boards(np.asarray(state).reshape(1, 4, 4))[0], b[0])
 
 
+def test_run_summary_has_the_reference_layout(pkg, tmp_path):
+    """summary.py: per-episode CSV (Agent/main.py:71-76 schema, numpy rows in the Q-Values
+    column as the reference writes them) -> the columns of plots/summary_statistics_cleaned.csv."""
+    import csv
+
+    rng = np.random.default_rng(5)
+    n = 500
+    actions = rng.integers(0, 4, n)
+    rewards = rng.normal(-0.3, 0.1, n)
+    maxes = 1 << rng.integers(5, 11, n)
+    path = tmp_path / "debug_log3.9.csv"
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Episode", "Action", "Q-Values", "Reward", "Total-Reward", "Max Value"])
+        for e in range(n):
+            w.writerow([e, int(actions[e]), rng.normal(size=4), float(rewards[e]), 12.5, int(maxes[e])])
+    row = pkg.summarize_csv(str(path))
+    assert pkg.SUMMARY_HEADER == ["Reward_Technique", "Avg_Reward", "Std_Reward", "Max_Value",
+                                  "Action_0", "Action_1", "Action_2", "Action_3"]
+    assert row[0] == "debug_log3.9" and row[3] == int(maxes.max())
+    assert row[1] == pytest.approx(rewards.mean(), rel=1e-12)
+    assert row[2] == pytest.approx(rewards.std(ddof=1), rel=1e-12)
+    assert row[4:] == np.bincount(actions, minlength=4).tolist() and sum(row[4:]) == n
+    out = tmp_path / "summary.csv"
+    pkg.write_summary([row, row], str(out))
+    lines = out.read_text().strip().splitlines()
+    assert lines[0] == ",".join(pkg.SUMMARY_HEADER) and len(lines) == 3
+    ref = "/root/reference/QLearningBase/plots/summary_statistics_cleaned.csv"
+    if os.path.exists(ref):                       # only where the reference is mounted
+        with open(ref) as fh:
+            assert fh.readline().strip() == lines[0]
+    with pytest.raises(ValueError):
+        pkg.summarize_episodes("x", [0, 4], [0.0, 1.0], [2, 4])
+    with pytest.raises(ValueError):
+        pkg.summarize_episodes("x", [], [], [])
+    tool = subprocess.run([sys.executable, os.path.join(REPO, "tools", "summarize_logs.py"), str(path),
+                           "-o", str(tmp_path / "s2.csv")], capture_output=True, text=True)
+    assert tool.returncode == 0 and tool.stdout.startswith("debug_log3.9,")
+
+
 _WORKER = r'''
 import importlib, os, sys
 import numpy as np, torch, torch.distributed as dist
