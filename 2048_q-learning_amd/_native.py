@@ -63,6 +63,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 _SIGNATURES = {
     "q2048_abi_version": (C.c_int, []),
     "q2048_strerror": (C.c_char_p, [C.c_int]),
+    "q2048_claim_timeouts": (C.c_int, [C.POINTER(C.c_uint64)]),
     "q2048_sizeof_aux": (C.c_size_t, []),
     "q2048_sizeof_slot": (C.c_size_t, []),
     "q2048_env_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint64,
@@ -143,6 +144,13 @@ def lib() -> C.CDLL:
         raise ImportError("ABI struct sizes changed")
     _lib = L
     return L
+
+
+def claim_timeouts() -> int:
+    """Lanes that ever gave up a bounded wait in the 5x5 row-creation protocol (expected: 0)."""
+    out = C.c_uint64(0)
+    check(lib().q2048_claim_timeouts(C.byref(out)), "q2048_claim_timeouts")
+    return int(out.value)
 
 
 def check(code: int, what: str) -> None:

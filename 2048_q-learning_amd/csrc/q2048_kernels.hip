@@ -128,7 +128,7 @@ __device__ __forceinline__ u64 key_home(const Geo<5>::Key& k, u64 mask) {
 // CUs' atomics never refresh); rows are claimed with a device-scope compare-and-swap on the key
 // word.  Keys are written once (0 -> key) and never change, so a stale read can only miss a
 // brand-new row, which reads as the zero row it still is for the reader.  5x5 keys take two
-// words, claimed one after the other without ever waiting for another lane (see `confirm`).
+// words: one compare-and-swap claims the first, its owner publishes the second (see `confirm`).
 // ---------------------------------------------------------------------------------------------
 struct Row { float q0, q1, q2, q3; };
 
@@ -145,29 +145,50 @@ __device__ __forceinline__ void row_set(Row& r, int a, float v) {
 }
 
 // `confirm`: the slot's first key word equals key.k0 (this lane just set it, or found it so).
-// Does the slot hold `key`?  4x4: yes.  5x5: the slot belongs to whoever sets the second word;
-// a lane that finds it still 0 completes the slot with its own second word by compare-and-swap
-// (`completed` = this lane created the row), so nobody ever waits for another lane's store --
-// wave-mates that lost the same claim included -- and the memory-side compare-and-swap also
-// settles a zero read from a stale L2 line.  The second word goes 0 -> value exactly once.
+// Does the slot hold `key`?  4x4: yes.  5x5 keys have a second word, and a claim is ONE
+// compare-and-swap (scattered device-scope atomics are the scarcest resource of the path: two per
+// new state made the 5x5 rollout 1.5x slower): the lane that won the first word publishes the
+// second with a write-through store at once; a lane that finds the first word equal and the
+// second still 0 waits for it.  Waiting is safe here because
+//   - the owner's store is issued directly after its compare-and-swap returns, before any
+//     wave-mate that lost the same compare-and-swap starts to wait (`wave_barrier` keeps the
+//     compiler from moving the two apart), and a lane of another wave never depends on this one;
+//   - the wait polls with a memory-side atomic (an L2-served load could show a stale 0 forever);
+//   - it is bounded: a lane that gives up counts in `g_claim_timeouts` (tests: always 0) and
+//     treats the slot as someone else's.
+// The second word goes 0 -> value exactly once, written only by the owner of the first.
+__device__ unsigned long long g_claim_timeouts;
+constexpr int kMaxAwait = 1 << 16;
+
+__device__ __forceinline__ u64 await_second(q2048_slot* s) {
+  u64* p = reinterpret_cast<u64*>(&s->reserved);
+  for (int spin = 0; spin < kMaxAwait; ++spin) {
+    const u64 hi = atomicCAS(p, 0ull, 0ull);  // reads at the memory side; writes nothing new
+    if (hi != 0ull) return hi;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  atomicAdd(&g_claim_timeouts, 1ull);
+  return 0ull;
+}
 __device__ __forceinline__ bool confirm(q2048_slot*, const Geo<4>::Key&, bool won, bool& completed) {
   completed = won;
   return true;
 }
 __device__ __forceinline__ bool confirm(q2048_slot* s, const Geo<5>::Key& key, bool won, bool& completed) {
-  completed = false;
-  u64 hi = won ? 0ull : ld_u64(&s->reserved);  // just claimed: the second word is 0 unless a helper was faster
-  if (hi == 0ull) {
-    hi = atomicCAS(reinterpret_cast<u64*>(&s->reserved), 0ull, key.k1);
-    if (hi == 0ull) { completed = true; return true; }
-  }
+  completed = won;
+  if (won)
+    __hip_atomic_store(reinterpret_cast<u64*>(&s->reserved), key.k1, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_wave_barrier();
+  if (won) return true;
+  u64 hi = ld_u64(&s->reserved);
+  if (hi == 0ull) hi = await_second(s);
   return hi == key.k1;
 }
 
 // Lookup.  Returns the slot index (>= 0) when the key is present; otherwise ~h (< 0) where h is
 // the empty slot that ended the probe -- the place an insert of this key would claim -- or
-// kNoSlot when the probe limit was hit.  `created` is set when this lane completed a half-made
-// 5x5 row on the way (it then owns a fresh zero row); it never is on 4x4.
+// kNoSlot when the probe limit was hit.  `created` stays false (lookups create nothing).
 constexpr int64_t kNoSlot = INT64_MIN;
 // The cost of the table is the NUMBER of scattered requests a lane issues, whatever line they
 // hit, so the probe reads {key, q0, q1} with ONE
@@ -202,7 +223,7 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
 
 // 5x5: {key, q0, q1} first; on a first-word match {q2, q3, second key word} -- two requests for
 // a hit instead of four (key, second word, two row halves).  A slot whose second word is still 0
-// is completed here exactly as `confirm` does.
+// is being created by its owner: wait for the word (`confirm`).
 __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
                                               const Geo<5>::Key& key, Row& row, bool& created) {
   u64 i = key_home(key, mask);
@@ -215,10 +236,7 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
     if (k == key.k0) {
       const u32x4 b = ld16_agent(&table[i].q[2]);
       u64 hi = (u64)b.z | ((u64)b.w << 32);
-      if (hi == 0ull) {
-        hi = atomicCAS(const_cast<u64*>(reinterpret_cast<const u64*>(&table[i].reserved)), 0ull, key.k1);
-        if (hi == 0ull) { created = true; return (int64_t)i; }  // this lane completed it: a zero row
-      }
+      if (hi == 0ull) hi = await_second(const_cast<q2048_slot*>(&table[i]));  // being created right now
       if (hi == key.k1) {
         row = Row{bits_f32(a.z), bits_f32(a.w), bits_f32(b.x), bits_f32(b.y)};
         return (int64_t)i;
@@ -248,57 +266,36 @@ __device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, con
   return kNoSlot;
 }
 
-// A row claim in flight.  The compare-and-swap is issued when the probe finds the state absent
-// and its result is consumed one step later, when s' has become s, so the round trip hides
-// behind the next step's arithmetic.  5x5 keys take two words: the second compare-and-swap is
-// issued as soon as the first has returned (after the env step) and is in flight during the
-// probe of the next state -- two dependent round trips in a row cost 2x the time of the whole
-// rest of the step when they were waited for in place.
-//   stage 0 idle, 1 first key word in flight, 2 second key word in flight (5x5), 3 the slot went
-//   to another key (5x5: found when the first word returned)
-struct Claim { u64 ret; u64 at; int stage; };
+// A row claim in flight (4x4).  The compare-and-swap is issued when the probe finds the state
+// absent and its result is consumed one step later, when s' has become s, so the round trip
+// hides behind the next step's arithmetic.  5x5 claims in place: the owner has to publish the
+// second key word right after the first (the shorter that window, the fewer lanes ever wait),
+// and its rollout is bound by request throughput, not latency (pipelining measured +-0).
+struct Claim { u64 ret; u64 at; bool active; };
 
-__device__ __forceinline__ void claim_issue(q2048_slot* table, int64_t slot, const Geo<4>::Key& key,
-                                            Claim& c) {
-  if (slot < 0 && slot != kNoSlot) {
+__device__ __forceinline__ int64_t claim_issue(q2048_slot* table, u64, int64_t slot,
+                                               const Geo<4>::Key& key, Claim& c, bool&) {
+  c.active = slot < 0 && slot != kNoSlot;
+  if (c.active) {
     c.at = (u64)~slot;
     c.ret = atomicCAS(reinterpret_cast<u64*>(&table[c.at].key), 0ull, key.k0);
-    c.stage = 1;
   }
+  return slot;
 }
-__device__ __forceinline__ void claim_issue(q2048_slot* table, int64_t slot, const Geo<5>::Key& key,
-                                            Claim& c) {
-  claim_issue(table, slot, Geo<4>::Key{key.k0}, c);
+__device__ __forceinline__ int64_t claim_issue(q2048_slot* table, u64 mask, int64_t slot,
+                                               const Geo<5>::Key& key, Claim& c, bool& inserted) {
+  c.active = false;
+  if (slot < 0 && slot != kNoSlot) return probe_insert(table, mask, key, (u64)~slot, inserted);
+  return slot;
 }
-__device__ __forceinline__ void claim_advance(q2048_slot*, const Geo<4>::Key&, Claim&) {}
-__device__ __forceinline__ void claim_advance(q2048_slot* table, const Geo<5>::Key& key, Claim& c) {
-  if (c.stage != 1) return;
-  if (c.ret == 0ull || c.ret == key.k0) {  // the first word is ours (or equal): settle the second
-    c.ret = atomicCAS(reinterpret_cast<u64*>(&table[c.at].reserved), 0ull, key.k1);
-    c.stage = 2;
-  } else {
-    c.stage = 3;
-  }
-}
-__device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, const Geo<4>::Key& key,
-                                                 Claim& c, int64_t slot, bool& inserted) {
-  if (c.stage == 0) return slot;
-  c.stage = 0;
+template <class Key>
+__device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, const Key& key, Claim& c,
+                                                 int64_t slot, bool& inserted) {
+  if (!c.active) return slot;
+  c.active = false;
   if (c.ret == 0ull) { inserted = true; return (int64_t)c.at; }
   if (c.ret == key.k0) return (int64_t)c.at;
   return probe_insert(table, mask, key, c.at + 1ull, inserted);  // another key took the slot
-}
-__device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, const Geo<5>::Key& key,
-                                                 Claim& c, int64_t slot, bool& inserted) {
-  if (c.stage == 0) return slot;
-  claim_advance(table, key, c);            // no-op unless the first word is still the last thing issued
-  const int stage = c.stage;
-  c.stage = 0;
-  if (stage == 2) {                        // the slot belongs to whoever set the second word (`confirm`)
-    if (c.ret == 0ull) { inserted = true; return (int64_t)c.at; }
-    if (c.ret == key.k1) return (int64_t)c.at;
-  }
-  return probe_insert(table, mask, key, c.at + 1ull, inserted);
 }
 
 // update_q_value on one entry (Agent/main.py:43) against its CURRENT value.  `guess` is the
@@ -568,8 +565,8 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
 //
 // Per step and lane the table sees: one probe of the next state (a read), at most one row claim
 // (compare-and-swap on the key word, only for a state reached for the first time) and one
-// 4-byte write of Q[s][a].  The claim of s' is issued as soon as the probe finds it absent and
-// consumed one step later, when s' has become s (5x5: first key word, then the second: `Claim`).  Rows appear exactly when the
+// 4-byte write of Q[s][a].  On 4x4 the claim of s' is issued as soon as the probe finds it absent
+// and consumed one step later, when s' has become s.  Rows appear exactly when the
 // reference's defaultdict creates them (q_table[next_state] / q_table[state] in
 // update_q_value, Agent/main.py:41-43).
 // ---------------------------------------------------------------------------------------------
@@ -601,7 +598,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
     Row q;
     bool made0 = false;
     int64_t slot_s = probe_find(table, mask, key_s, q, made0);
-    Claim claim{0ull, 0ull, 0};
+    Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
     uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = wave_count(made0), n_drop = 0;
     uint32_t retries = 0;
@@ -616,19 +613,16 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
       const bool same = key_eq(key_n, key_s);
       // the row of s: claimed one step ago (in flight since), or now if s opened the episode/launch
       bool ins_s = false, ins_n = false;
-      if constexpr (N == 4) slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_s);
-      else claim_advance(table, key_s, claim);      // second key word: in flight during the probe
+      slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_s);
+      if (slot_s < 0 && slot_s != kNoSlot && !x_noclaim)   // s opened the episode / launch
+        slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
       // q_table[next_state] (:41)
       Row qn = q;
-      int64_t slot_n = kNoSlot;
+      int64_t slot_n = slot_s;
       if (!same) {
         if (x_noprobe) { qn = Row{0.f, 0.f, 0.f, 0.f}; slot_n = ~(int64_t)key_home(key_n, mask); }
         else slot_n = probe_find(table, mask, key_n, qn, ins_n);
       }
-      if constexpr (N == 5) slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_s);
-      if (slot_s < 0 && slot_s != kNoSlot && !x_noclaim)   // s opened the episode / launch
-        slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
-      if (same) slot_n = slot_s;
       const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
       float nq = 0.f;
       const bool updated = slot_s >= 0;
@@ -664,7 +658,11 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
         else slot_s = kNoSlot;      // dropped: do not retry the claim with a stale hint
       } else {
         key_s = key_n; slot_s = slot_n; q = qn;                                        // :100
-        if (!x_noclaim) claim_issue(table, slot_s, key_s, claim);
+        if (!x_noclaim) {
+          bool made = false;
+          slot_s = claim_issue(table, mask, slot_s, key_s, claim, made);
+          ins_n = ins_n || made;
+        }
       }
       n_valid += wave_count(o.valid != 0);
       n_explore += wave_count(explored);
@@ -1007,6 +1005,14 @@ inline int check_table(const void* table, int cap_log2) {
 extern "C" {
 
 int q2048_abi_version(void) { return Q2048_ABI_VERSION; }
+
+int q2048_claim_timeouts(uint64_t* count_host) {
+  if (count_host == nullptr) return Q2048_ERR_NULL;
+  unsigned long long v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_claim_timeouts), sizeof(v)) != hipSuccess) return Q2048_ERR_LAUNCH;
+  *count_host = (uint64_t)v;
+  return Q2048_OK;
+}
 size_t q2048_sizeof_aux(void) { return sizeof(q2048_aux); }
 size_t q2048_sizeof_slot(void) { return sizeof(q2048_slot); }
 

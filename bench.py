@@ -234,7 +234,7 @@ def main():
         "stats": {"episodes": st["episodes"], "mean_return": st["mean_return"],
                   "mean_score": st["mean_score"], "valid_move_frac": st["valid_moves"] / max(st["steps"], 1),
                   "table_inserts": st["inserts"], "drops": st["drops"],
-                  "table_rows_per_gpu": table_rows,
+                  "table_rows_per_gpu": table_rows, "claim_timeouts": pkg._native.claim_timeouts(),
                   "table_load_factor": None if table_rows is None else table_rows / float(1 << cap_log2),
                   "cas_retries": st["cas_retries"], "status": status,
                   "max_tile_hist": {str(k): v for k, v in st["max_tile_hist"].items()}},

@@ -114,6 +114,11 @@ enum {
 enum { Q2048_SF_RETURN = 0, Q2048_SF_RETURN_SQ = 1, Q2048_SF_REWARD = 2, Q2048_NSTAT_F = 4 };
 
 int q2048_abi_version(void);
+
+/* Diagnostic, host-synchronous: lanes of the current device that ever gave up waiting for the
+ * second key word of a 5x5 row under creation (the wait is bounded so that a protocol error can
+ * never hang the device).  Expected value: 0, always; the tests assert it. */
+int q2048_claim_timeouts(uint64_t *count_host);
 const char *q2048_strerror(int code);
 size_t q2048_sizeof_aux(void);  /* 16 */
 size_t q2048_sizeof_slot(void); /* 32 */

@@ -1127,3 +1127,24 @@ def test_device_spanning_table_uses_64_bit_slot_indices(pkg):
     assert q.shape == (4096, 4) and bool(torch.isfinite(q).all())
     del agent, env, upper
     torch.cuda.empty_cache()
+
+
+def test_5x5_contended_creation_never_times_out(pkg, O):
+    """Many lanes create the SAME 5x5 rows at the same time (every env starts from one of a few
+    hundred boards): one compare-and-swap per row, the owner publishes the second key word,
+    everybody else waits for it.  No duplicates, no lost rows, and no lane ever gave up waiting --
+    here or in any earlier test of this process."""
+    B, steps = 1 << 16, 6
+    env = pkg.BatchedGame2048Env(B, board_size=5, seed=21, device=DEV)
+    agent = pkg.BatchedQLearningAgent(10, exploration_rate=1.0, capacity_log2=22, seed=21, device=DEV,
+                                      board_size=5)
+    agent.fused_rollout(env, steps)
+    envs = O.envs_init(B, 5, 21, 0)
+    oa = O.Agent(10, 4, 0.1, 0.9, 1.0, n=5)
+    O.rollout(envs, oa, steps, 21, 0, 0)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :25])
+    st = agent.stats()
+    assert st["drops"] == 0 and agent.table_size() == st["inserts"] == len(oa)   # the dict's key set size
+    keys, _ = agent.export_rows()
+    assert len(np.unique(keys, axis=0)) == len(keys)                              # no duplicate rows
+    assert pkg._native.claim_timeouts() == 0

@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t grind(uint32_t a, uint32_t b, int work) {
   return a ^ b;
 }
 
-enum { kLoad = 1, kCas = 2, kStore = 4, kCasAlways = 8, kStore16 = 16, kStore32 = 32 };
+enum { kLoad = 1, kCas = 2, kStore = 4, kCasAlways = 8, kStore16 = 16, kStore32 = 32, kCas2 = 64, kKey16 = 128 };
 
 __global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, int64_t lanes, int steps,
                                                   int what, int work, uint32_t ctr0, uint32_t* sink) {
@@ -64,6 +64,12 @@ __global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, in
     if ((what & kCasAlways) || ((what & kCas) && seen == 0ull)) {
       const uint64_t r = atomicCAS(&table[at].key, 0ull, key);
       acc ^= (uint32_t)r;                       // the result is consumed (like the real claim)
+      if (what & kCas2) {                       // a second word of the same row (two-word keys)
+        const uint64_t r2 = atomicCAS(&table[at].pad, 0ull, key ^ 0x5555ull);
+        acc ^= (uint32_t)r2;
+      }
+      if (what & kKey16)                        // ... or the key body written by one 16-B store
+        reinterpret_cast<uint4*>(&table[at])[1] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), acc | 1u, 7u);
     }
     if (what & kStore) *reinterpret_cast<uint32_t*>(&table[prev].q[key & 3ull]) = acc;
     if (what & (kStore16 | kStore32)) {        // whole 16-B half / whole 32-B row (no partial sector)
@@ -100,7 +106,9 @@ int main(int argc, char** argv) {
       {"load+cas", kLoad | kCas}, {"load+store", kLoad | kStore},
       {"load+cas+store", kLoad | kCas | kStore}, {"cas(always)+store", kCasAlways | kStore},
       {"store16", kStore16}, {"store32", kStore32}, {"load+store32", kLoad | kStore32},
-      {"load+cas+store32", kLoad | kCas | kStore32}};
+      {"load+cas+store32", kLoad | kCas | kStore32},
+      {"load+cas+cas2+store", kLoad | kCas | kCas2 | kStore},
+      {"load+cas+key16+store", kLoad | kCas | kKey16 | kStore}};
   std::printf("{\"alloc_log2\": %d, \"cap_log2\": %d, \"lanes\": %lld, \"steps\": %d, \"unit\": \"us per step per 2^20 lanes\", \"rows\": [\n",
               alloc_log2, cap_log2, (long long)lanes, steps);
   bool first = true;
