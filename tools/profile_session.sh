@@ -31,6 +31,9 @@ echo "== ablation + env-only kernel"
 timeout -k 10 600 python tools/exp_ablate.py 2> /dev/null | tee "$OUT/ablate.jsonl"
 timeout -k 10 300 python tools/exp_variants.py 2> /dev/null | head -n 2 | tee "$OUT/env_only.jsonl"
 echo "== train.py smoke"
-timeout -k 10 300 python train.py --num-envs 1 --episodes 3 --log "$OUT/train_single.csv" 2>&1 | tail -n 3
+timeout -k 10 300 python train.py --num-envs 1 --episodes 3 --log "$OUT/train_single.csv" --summary "$OUT/train_single_summary.csv" 2>&1 | tail -n 3
+cat "$OUT/train_single_summary.csv"
+timeout -k 10 300 python train.py --num-envs 16384 --board-size 5 --episodes 2 --steps-per-launch 32 --report-every 8 --log "$OUT/train_5x5.csv" --episode-log "$OUT/train_5x5_episodes.csv" --summary "$OUT/train_5x5_summary.csv" 2>&1 | tail -n 2
+cat "$OUT/train_5x5_summary.csv"
 timeout -k 10 300 python train.py --num-envs 65536 --episodes 3 --steps-per-launch 32 --report-every 4 --log "$OUT/train_batched.csv" 2>&1 | tail -n 4
 head -n 4 "$OUT/train_single.csv" "$OUT/train_batched.csv"
