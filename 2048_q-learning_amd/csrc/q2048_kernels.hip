@@ -150,9 +150,10 @@ __device__ __forceinline__ void row_set(Row& r, int a, float v) {
 // new state made the 5x5 rollout 1.5x slower): the lane that won the first word publishes the
 // second with a write-through store at once; a lane that finds the first word equal and the
 // second still 0 waits for it.  Waiting is safe here because
-//   - the owner's store is issued directly after its compare-and-swap returns, before any
-//     wave-mate that lost the same compare-and-swap starts to wait (`wave_barrier` keeps the
-//     compiler from moving the two apart), and a lane of another wave never depends on this one;
+//   - a lane is waited for only from the moment its compare-and-swap has succeeded, and its
+//     store is the next thing its wave issues: ahead of the wait of any wave-mate that lost the
+//     same compare-and-swap (`wave_barrier` keeps the compiler from moving the two apart), and
+//     the owner itself waits for nobody in between -- so there is no cycle of waits;
 //   - the wait polls with a memory-side atomic (an L2-served load could show a stale 0 forever);
 //   - it is bounded: a lane that gives up counts in `g_claim_timeouts` (tests: always 0) and
 //     treats the slot as someone else's.
