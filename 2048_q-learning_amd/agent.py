@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 from . import _native as N
-from .env import BatchedGame2048Env, _ptr, _require_gpu, _stream, raw_to_boards
+from .env import (BatchedGame2048Env, _ptr, _require_gpu, _Staging, _stream, raw_to_boards,
+                  state_to_log2)
 
 
 class EpsilonSchedule:
@@ -549,9 +550,34 @@ def stats_dict(si, sf) -> dict:
     }
 
 
+class _OneStateTable:
+    """`agent.q_table[state]` / `len(agent.q_table)` of the one-state adapter: the same lookups
+    as `_QTableView`, moved through the adapter's staging buffer (one copy in, one out)."""
+
+    def __init__(self, owner: "QLearningAgent"):
+        self._o = weakref.proxy(owner)
+
+    def __getitem__(self, state) -> np.ndarray:
+        o = self._o
+        io, b = o._io, o._b
+        state_to_log2(state, io.np_in[0:16])
+        io.upload(16)
+        N.check(N.lib().q2048_q_lookup(
+            _ptr(b.table), b.capacity_log2, io.ptr, 1, 4, b.env_id0, b.flags | N.FLAG_SINGLE_ENV,
+            io.ptr + 48, None, _ptr(b.status), _stream(b.device)), "q_lookup")
+        io.download(48, 64)
+        io.sync()
+        return io.np_out[48:64].view(np.float32).astype(np.float64)
+
+    def __len__(self) -> int:
+        return self._o._b.table_size()
+
+
 class QLearningAgent:
     """One-state adapter with the reference's exact surface (Agent/main.py:14-57): states are
-    tuples of tuples of raw tile values, actions Python ints."""
+    tuples of tuples of raw tile values, actions Python ints.  Every call moves its few bytes
+    through one 64-byte staging buffer: [0:16] state, [16:32] next state, [32] action, [33] done,
+    [36:40] reward, [40] chosen action, [48:64] a Q row."""
 
     def __init__(self, total_epochs, action_space, learning_rate=0.1, discount_factor=0.9,
                  exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 22,
@@ -559,7 +585,8 @@ class QLearningAgent:
         self._b = BatchedQLearningAgent(total_epochs, action_space, learning_rate, discount_factor,
                                         exploration_rate, exploration_min, capacity_log2, device,
                                         seed, env_id)
-        self.q_table = self._b.q_table
+        self._io = _Staging(self._b.device)
+        self.q_table = _OneStateTable(self)
         self.action_space = action_space
         self.total_epochs = total_epochs
 
@@ -575,17 +602,32 @@ class QLearningAgent:
     def epsilon(self, v):
         self._b.epsilon = v
 
-    def _state(self, state) -> torch.Tensor:
-        return torch.from_numpy(raw_to_boards(np.asarray(state).reshape(1, 4, 4)))
-
     def choose_action(self, state) -> int:
-        return int(self._b.choose_action(self._state(state)).item())
+        io, b = self._io, self._b
+        state_to_log2(state, io.np_in[0:16])
+        io.upload(16)
+        N.check(N.lib().q2048_q_choose(
+            _ptr(b.table), b.capacity_log2, io.ptr, 1, 4, float(b.epsilon), b.seed, b.env_id0,
+            b.ctr & 0xFFFFFFFF, b.flags, io.ptr + 40, _ptr(b.status), _stream(b.device)), "q_choose")
+        b.ctr += 1
+        io.download(40, 41)
+        io.sync()
+        return int(io.np_out[40])
 
     def update_q_value(self, state, action, reward, next_state, done) -> None:
         if not 0 <= int(action) <= 3:
             raise ValueError(f"action {action} outside 0..3")
-        self._b.update_q_value(self._state(state), [int(action)], [float(reward)],
-                               self._state(next_state), [bool(done)])
+        io, b = self._io, self._b
+        buf = io.np_in
+        state_to_log2(state, buf[0:16])
+        state_to_log2(next_state, buf[16:32])
+        buf[32], buf[33] = int(action), 1 if done else 0
+        buf[36:40].view(np.float32)[0] = reward
+        io.upload(40)
+        N.check(N.lib().q2048_q_update(
+            _ptr(b.table), b.capacity_log2, io.ptr, io.ptr + 32, io.ptr + 36, io.ptr + 16, io.ptr + 33,
+            1, 4, float(b.lr), float(b.gamma), b.env_id0, b.flags, _ptr(b.stats_i), _ptr(b.status),
+            _stream(b.device)), "q_update")
 
     def decay_exploration(self, current_epoch) -> None:
         self._b.decay_exploration(current_epoch)

@@ -204,6 +204,46 @@ class _Game:
         return boards_to_raw(self._env._b.boards.cpu().numpy())[0]
 
 
+_LOG2_OF = {0: 0, **{1 << k: k for k in range(1, 32)}}
+
+
+def state_to_log2(state, out: np.ndarray) -> None:
+    """One reference state (4 x 4 raw tile values: array or tuple of tuples) -> 16 log2 bytes in
+    `out`; the scalar twin of raw_to_boards for the one-env adapters."""
+    k = 0
+    try:
+        for row in state:
+            for v in row:
+                out[k] = _LOG2_OF[int(v)]
+                k += 1
+    except KeyError:
+        raise ValueError("board holds a value that is not a power of two") from None
+    if k != 16:
+        raise ValueError("a state is a 4 x 4 board")
+
+
+class _Staging:
+    """64 bytes on the device + their pinned host mirror: the one-env adapters move their few
+    bytes with one copy in, one copy out and one stream synchronisation per call."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.dev = torch.zeros(64, dtype=torch.uint8, device=device)
+        self.host_in = torch.zeros(64, dtype=torch.uint8)                 # pageable: reusable at once
+        self.host_out = torch.zeros(64, dtype=torch.uint8).pin_memory()
+        self.np_in, self.np_out = self.host_in.numpy(), self.host_out.numpy()
+        self.ptr = self.dev.data_ptr()
+
+    def upload(self, nbytes: int) -> None:
+        self.dev[:nbytes].copy_(self.host_in[:nbytes])
+
+    def download(self, lo: int, hi: int) -> None:
+        self.host_out[lo:hi].copy_(self.dev[lo:hi], non_blocking=True)
+
+    def sync(self) -> None:
+        torch.cuda.current_stream(self.device).synchronize()
+
+
 class Game2048_env:
     """One env with the reference's exact surface and Python types
     (Game2048_env.py:78-205): reset() -> int64[4,4], step(a) -> (board, float, bool, int)."""
@@ -212,17 +252,33 @@ class Game2048_env:
         self._b = BatchedGame2048Env(1, 4, device, seed, env_id)
         self.action_space = self._b.action_space
         self.game = _Game(self)
+        self._io = _Staging(self._b.device)          # [0:16] board, [16:20] reward, [20] done, [21] max
+        self._acts = torch.arange(4, dtype=torch.uint8, device=self._b.device)
+
+    def _board_out(self) -> np.ndarray:
+        io, b = self._io, self._b
+        io.host_out[0:16].copy_(b.boards.view(-1), non_blocking=True)
+        io.sync()
+        return boards_to_raw(io.np_out[0:16])
 
     def reset(self) -> np.ndarray:
         self._b.reset()
-        return self.game.board
+        return self._board_out()
 
     def step(self, action: int):
-        if not 0 <= int(action) <= 3:
+        action = int(action)
+        if not 0 <= action <= 3:
             raise ValueError(f"action {action} outside 0..3")
-        act = torch.tensor([int(action)], dtype=torch.uint8, device=self._b.device)
-        _, r, d, m = self._b.step(act)
-        return self.game.board, float(r.item()), bool(d.item()), int(m.item())
+        io, b = self._io, self._b
+        N.check(N.lib().q2048_env_step(
+            _ptr(b.boards), _ptr(b.aux), self._acts.data_ptr() + action, 1, 4, b.seed, b.env_id0,
+            b.ctr & 0xFFFFFFFF, io.ptr + 16, io.ptr + 20, io.ptr + 21, _ptr(b.status),
+            _stream(b.device)), "env_step")
+        b.ctr += 1
+        io.download(16, 22)
+        board = self._board_out()                                    # + the synchronisation
+        out = io.np_out
+        return board, float(out[16:20].view(np.float32)[0]), bool(out[20]), 1 << int(out[21])
 
     @property
     def score(self) -> int:
