@@ -2,6 +2,7 @@
 declares, host logic (epsilon schedule, sharding, statistics all-reduce over gloo with
 world_size 2), loud failure without a device, and no product import of the oracle."""
 import ctypes as C
+import importlib
 import json
 import os
 import re
@@ -108,6 +109,18 @@ def test_board_conversions(pkg):
     assert pkg.boards_to_raw(np.array([[1, 0, 2] + [0] * 13]))[0, 0].tolist() == [2, 0, 4, 0]
     with pytest.raises(ValueError):
         pkg.raw_to_boards(np.full((4, 4), 3))
+    # the scalar twin used by the one-env adapters: arrays and tuples of tuples alike
+    env_mod = importlib.import_module("2048_q-learning_amd.env")
+    out = np.zeros(16, dtype=np.uint8)
+    for k in range(50):
+        env_mod.state_to_log2(raw[k], out)
+        assert np.array_equal(out, b[k])
+        env_mod.state_to_log2(tuple(map(tuple, raw[k].tolist())), out)
+        assert np.array_equal(out, b[k])
+    with pytest.raises(ValueError):
+        env_mod.state_to_log2(np.full((4, 4), 3), out)
+    with pytest.raises(ValueError):
+        env_mod.state_to_log2(np.zeros((3, 4), dtype=int), out)
     state = tuple(map(tuple, raw[0]))
     assert np.array_equal(pkg.raw_to_boards(np.asarray(state).reshape(1, 4, 4))[0], b[0])
 
