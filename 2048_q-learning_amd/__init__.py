@@ -14,14 +14,15 @@ from ._native import NativeError, build
 from .agent import (EPISODE_DTYPE, BatchedQLearningAgent, BatchedRowTupleAgent, EpisodeLog,
                     EpsilonSchedule, QLearningAgent, auto_capacity_log2, place_table,
                     stats_dict)
-from .dist import Shard, allreduce_stats, shard_plan, weak_shard
+from . import launch
+from .dist import Shard, StatsAllReduce, allreduce_stats, shard_plan, weak_shard
 from .summary import SUMMARY_HEADER, summarize_csv, summarize_episodes, summarize_records, write_summary
 from .env import (AUX_DTYPE, BatchedGame2048Env, Game2048_env, boards_to_raw, raw_to_boards)
 
 __all__ = [
     "BatchedGame2048Env", "Game2048_env", "BatchedQLearningAgent", "BatchedRowTupleAgent",
     "QLearningAgent",
-    "EpsilonSchedule", "EpisodeLog", "EPISODE_DTYPE", "stats_dict", "Shard", "shard_plan", "weak_shard", "allreduce_stats",
+    "EpsilonSchedule", "EpisodeLog", "EPISODE_DTYPE", "stats_dict", "Shard", "shard_plan", "weak_shard", "allreduce_stats", "StatsAllReduce", "launch",
     "boards_to_raw", "raw_to_boards", "AUX_DTYPE", "build", "NativeError", "place_table", "auto_capacity_log2",
     "SUMMARY_HEADER", "summarize_csv", "summarize_episodes", "summarize_records", "write_summary",
 ]

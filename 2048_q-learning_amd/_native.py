@@ -20,6 +20,8 @@ DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.in
 OK = 0
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
 FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
+FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY = 8, 16, 32
+ABI_VERSION = 2
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
 ST_HIST0, NSTAT_I = 8, 32
 SF_RETURN, SF_RETURN_SQ, SF_REWARD, NSTAT_F = 0, 1, 2, 4
@@ -70,6 +72,11 @@ _SIGNATURES = {
                                  C.c_uint64, C.c_void_p]),
     "q2048_env_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                   C.c_uint64, C.c_uint64, C.c_void_p]),
+    "q2048_env_reset_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                     C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "q2048_env_step_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                    C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "q2048_env_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                  C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -138,8 +145,8 @@ def lib() -> C.CDLL:
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the ABI is incomplete
         fn.restype, fn.argtypes = res, args
-    if L.q2048_abi_version() != 1:
-        raise ImportError(f"ABI version {L.q2048_abi_version()} != 1")
+    if L.q2048_abi_version() != ABI_VERSION:
+        raise ImportError(f"ABI version {L.q2048_abi_version()} != {ABI_VERSION}")
     if L.q2048_sizeof_aux() != SIZEOF_AUX or L.q2048_sizeof_slot() != SIZEOF_SLOT:
         raise ImportError("ABI struct sizes changed")
     _lib = L

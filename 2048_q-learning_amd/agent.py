@@ -85,7 +85,8 @@ class _QTableView:
         self._a = weakref.proxy(agent)  # no reference cycle: the table frees with the agent
 
     def __getitem__(self, state) -> np.ndarray:
-        b = torch.from_numpy(raw_to_boards(np.asarray(state).reshape(1, 4, 4))).to(self._a.device)
+        n = self._a.board_size
+        b = torch.from_numpy(raw_to_boards(np.asarray(state).reshape(1, n, n))).to(self._a.device)
         return self._a.q_values(b, env_id=self._a.env_id0)[0].double().cpu().numpy()
 
     def __len__(self) -> int:
@@ -261,11 +262,14 @@ class BatchedQLearningAgent:
         return (q, found.bool()) if return_found else q
 
     # -- throughput entry point ----------------------------------------------------------
-    def fused_rollout(self, env: BatchedGame2048Env, steps: int, episode_log: "EpisodeLog | None" = None) -> None:
+    def fused_rollout(self, env: BatchedGame2048Env, steps: int, episode_log: "EpisodeLog | None" = None,
+                      play_only: bool = False) -> None:
         """`steps` iterations of choose -> step -> update -> accumulate -> reset-on-done
         (Agent/main.py:91-101, :81) for every env in ONE launch.  Statistics accumulate in
         `stats_i` / `stats_f` on the device (read them with `stats()`); with `episode_log` every
-        finished episode also leaves one record (the reference's CSV row, :103-105)."""
+        finished episode also leaves one record (the reference's CSV row, :103-105).  The env's
+        profile flags travel with the call.  `play_only`: no learner -- the table is neither read
+        nor written (every row reads as zeros); with epsilon = 1 that is uniformly random play."""
         if env.device != self.device:
             raise ValueError("env and agent live on different devices")
         if (env.seed, env.env_id0) != (self.seed, self.env_id0):
@@ -278,7 +282,8 @@ class BatchedQLearningAgent:
         N.check(N.lib().q2048_fused_rollout_log(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
             self.board_size, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
-            self.env_id0, self.ctr & 0xFFFFFFFF, self.flags | self.experiment_bits,
+            self.env_id0, self.ctr & 0xFFFFFFFF,
+            self.flags | self.experiment_bits | env.env_flags | (N.FLAG_PLAY_ONLY if play_only else 0),
             _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status),
             _ptr(log.records) if log is not None else None, log.capacity if log is not None else 0,
             _ptr(log.count) if log is not None else None, _stream(self.device)), "fused_rollout")
@@ -415,10 +420,11 @@ class BatchedQLearningAgent:
             raise ValueError("table too small for the checkpoint (load factor would exceed 0.5)")
         tk = torch.from_numpy(keys.view(np.int64)).to(self.device)
         tq = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.device)
-        N.check(N.lib().q2048_table_import(_ptr(self.table), self.capacity_log2, _ptr(tk), _ptr(tq),
-                                           rows, keys.shape[1], _ptr(self.status),
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)   # this call's own word: the
+        N.check(N.lib().q2048_table_import(_ptr(self.table), self.capacity_log2, _ptr(tk), _ptr(tq),  # agent's
+                                           rows, keys.shape[1], _ptr(status),                          # is sticky
                                            _stream(self.device)), "table_import")
-        if int(self.status.item()) & N.STATUS_TABLE_FULL:
+        if int(status.item()) & N.STATUS_TABLE_FULL:
             raise RuntimeError("table_import dropped rows (probe limit)")
 
     # -- argument plumbing -----------------------------------------------------------------

@@ -36,7 +36,7 @@ namespace q2048 {
 // key = (seed lo, seed hi).  One call serves one env step:
 //   x[0] epsilon test, x[1] random action, x[2] spawn cell, x[3] spawn value.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kStreamStep = 0u, kStreamReset = 1u;
+constexpr uint32_t kStreamStep = 0u, kStreamReset = 1u, kStreamOver = 2u;
 
 struct Draws { uint32_t x0, x1, x2, x3; };
 
@@ -328,6 +328,64 @@ Q_HD StepOut env_step(BoardT& b, Aux& a, int action, uint32_t x_pos, uint32_t x_
   return o;
 }
 
+// Env profiles (template parameter ENV of the kernels = Q2048_FLAG_ENV_DQN / _RESET_SHAPING >> 3):
+//   kEnvDqn           step of the DQN path's env, Deep_QLearning/environment/
+//                     Game2048_nopenalty_env.py:106-138, instead of Game2048_env.step
+//   kEnvResetShaping  resets also restore previous_max and the consecutive-action state
+//                     (SURVEY 7.8 opt-in; Game2048_env.reset, :187-191, leaves them alone)
+constexpr int kEnvDqn = 1, kEnvResetShaping = 2;
+
+// Game2048_nopenalty_env.step (:106-120) with the caller's `env.game.board = next_state`
+// (mainDQL_CNN_step2.py:237) folded in: on return b is moved_board.
+//   - move works on a copy (:58); is_game_over (:68-78) inspects the board from BEFORE the move:
+//     False if it has an empty cell (:70-71); on a full board it makes real moves 0..3 (:72-74) and
+//     the first that changes something leaves ITS result, spawn included (draws y_pos, y_val), in
+//     moved_board (:75-77) -- that, not the chosen action's move, is what the step returns;
+//   - reward = calculate_reward2 (:122-138): -10 for an invalid move while not over, else the
+//     chosen move's merge score; done = game_over (:117-118); max tile of moved_board (:109).
+template <class BoardT>
+Q_HD StepOut env_step_dqn(BoardT& b, Aux& a, int action, uint32_t x_pos, uint32_t x_val,
+                          uint32_t y_pos, uint32_t y_val) {
+  StepOut o;
+  const BoardT pre = b;
+  uint32_t score;
+  const bool valid = move(b, action, score);                            // :107 -> :53-63
+  if (valid) spawn(b, x_pos, x_val);                                    // :64-65
+  bool over = false;
+  if (empty_mask(pre) == 0u) {                                          // :70
+    over = true;
+    for (int act = 0; act < 4 && over; ++act) {                         // :72
+      BoardT t = pre;                                                   // :58
+      uint32_t s2;
+      if (move(t, act, s2)) {                                           // :74
+        spawn(t, y_pos, y_val);                                         // :64-65
+        b = t;
+        over = false;                                                   // :75-77
+      }
+    }
+    if (over) b = pre;                      // nothing moved: moved_board is a copy of the board
+  }
+  const uint32_t mx = max_log2(b);                                      // :109
+  a.score += (int32_t)score;                                            // :112
+  const double r = (!valid && !over) ? -10.0 : (double)score;           // :125-128
+  o.reward64 = r;
+  o.reward = (float)r;
+  a.ep_return += o.reward;
+  o.score = score;
+  o.done = over;                                                        // :117-118
+  o.max_log2 = (uint8_t)mx;
+  o.valid = valid;
+  return o;
+}
+
+// the step of profile ENV; (y_pos, y_val) are only used by kEnvDqn
+template <int ENV, class BoardT>
+Q_HD StepOut env_step_profile(BoardT& b, Aux& a, int action, uint32_t x_pos, uint32_t x_val,
+                              uint32_t y_pos, uint32_t y_val) {
+  if constexpr ((ENV & kEnvDqn) != 0) return env_step_dqn(b, a, action, x_pos, x_val, y_pos, y_val);
+  else return env_step(b, a, action, x_pos, x_val);
+}
+
 // Game2048.__init__ (:11-14) / Game2048_env.reset (:187-191): empty board, two spawns,
 // score = 0.  previous_max and the consecutive-action state are NOT reset (:187-191).
 template <class BoardT>
@@ -347,9 +405,15 @@ Q_HD void init_env(BoardT& b, Aux& a, uint64_t seed, uint64_t env_id) {
   reset_board(b, a, draws(seed, env_id, 0u, kStreamReset));
 }
 template <class BoardT>
-Q_HD void begin_episode(BoardT& b, Aux& a, uint64_t seed, uint64_t env_id) {
+Q_HD void begin_episode(BoardT& b, Aux& a, uint64_t seed, uint64_t env_id,
+                        bool reset_shaping = false) {
   a.episode += 1u;
   reset_board(b, a, draws(seed, env_id, a.episode, kStreamReset));
+  if (reset_shaping) {            // what Game2048_env.__init__ sets (:87, :92-93)
+    a.prev_max = 1;
+    a.cons_action = kNoAction;
+    a.cons_count = 0;
+  }
 }
 
 // register <-> memory images (little endian): board = 16 bytes, aux = 16 bytes

@@ -388,24 +388,29 @@ __global__ __launch_bounds__(kBlock) void k_env_init(uint8_t* boards, q2048_aux*
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_env_reset(uint8_t* boards, q2048_aux* aux,
                                                       const uint8_t* mask, int64_t B, uint64_t seed,
-                                                      uint64_t env_id0) {
+                                                      uint64_t env_id0, uint32_t flags) {
   __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   auto b = load_board(boards, i, B, st);
   if (i < B && (mask == nullptr || mask[i] != 0)) {
     Aux a = ld_aux(aux, i);
-    begin_episode(b, a, seed, env_id0 + (uint64_t)i);
+    begin_episode(b, a, seed, env_id0 + (uint64_t)i, (flags & Q2048_FLAG_RESET_SHAPING) != 0);
     st_aux(aux, i, a);
   }
   store_board(boards, i, B, b, st);
 }
 
-template <int N>
+// ENV: env profile bits (kEnvDqn: the DQN path's step).  draw_pos != nullptr: injected draws,
+// element i * draw_stride of draw_pos / draw_val (and, for kEnvDqn, draw_opos / draw_oval: the
+// spawn inside is_game_over's move).
+template <int N, int ENV>
 __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux* aux,
                                                      const uint8_t* actions, int64_t B, uint64_t seed,
                                                      uint64_t env_id0, uint32_t ctr, float* reward,
                                                      uint8_t* done, uint8_t* max_l2, uint32_t* status,
-                                                     const uint32_t* draw_pos, const uint32_t* draw_val) {
+                                                     const uint32_t* draw_pos, const uint32_t* draw_val,
+                                                     const uint32_t* draw_opos, const uint32_t* draw_oval,
+                                                     int draw_stride) {
   __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   auto b = load_board(boards, i, B, st);
@@ -416,10 +421,15 @@ __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux*
       reward[i] = 0.f; done[i] = 0; max_l2[i] = 0;
     } else {
       Aux a = ld_aux(aux, i);
-      Draws x;
-      if (draw_pos != nullptr) { x.x2 = draw_pos[i]; x.x3 = draw_val[i]; }  // injected (parity tests)
-      else x = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamStep);
-      const StepOut o = env_step(b, a, act, x.x2, x.x3);
+      Draws x, y{0u, 0u, 0u, 0u};
+      if (draw_pos != nullptr) {  // injected (parity tests)
+        x.x2 = draw_pos[i * draw_stride]; x.x3 = draw_val[i * draw_stride];
+        if constexpr ((ENV & kEnvDqn) != 0) { y.x0 = draw_opos[i * draw_stride]; y.x1 = draw_oval[i * draw_stride]; }
+      } else {
+        x = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamStep);
+        if constexpr ((ENV & kEnvDqn) != 0) y = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamOver);
+      }
+      const StepOut o = env_step_profile<ENV>(b, a, act, x.x2, x.x3, y.x0, y.x1);
       st_aux(aux, i, a);
       reward[i] = o.reward; done[i] = o.done; max_l2[i] = o.max_log2;
     }
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
 #ifndef Q2048_FUSED_MIN_WAVES
 #define Q2048_FUSED_MIN_WAVES 6
 #endif
-template <int N>
+template <int N, int ENV>
 __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
     double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
@@ -592,13 +602,15 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
     const uint64_t id = env_id0 + (uint64_t)i;
     const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
     const uint32_t td_mode = td_mode_of(flags);
-    // experiment bits (not ABI): 12 no row creation, 13 no next-state probe
-    const bool x_noclaim = (flags >> 12) & 1u, x_noprobe = (flags >> 13) & 1u;
+    // Q2048_FLAG_PLAY_ONLY: the table is never touched (every row reads as zeros, nothing is
+    // created or written).  Experiment bits (not ABI): 12 no row creation, 13 no next-state probe
+    const bool play_only = (flags & Q2048_FLAG_PLAY_ONLY) != 0;
+    const bool x_noclaim = ((flags >> 12) & 1u) || play_only, x_noprobe = ((flags >> 13) & 1u) || play_only;
     Aux a = ld_aux(aux, i);
     auto key_s = state_key(b, salt, status);
-    Row q;
+    Row q{0.f, 0.f, 0.f, 0.f};
     bool made0 = false;
-    int64_t slot_s = probe_find(table, mask, key_s, q, made0);
+    int64_t slot_s = play_only ? kNoSlot : probe_find(table, mask, key_s, q, made0);
     Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
     uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = wave_count(made0), n_drop = 0;
@@ -607,9 +619,11 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
 
     for (int t = 0; t < steps; ++t) {
       const Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
+      Draws y{0u, 0u, 0u, 0u};
+      if constexpr ((ENV & kEnvDqn) != 0) y = draws(seed, id, ctr0 + (uint32_t)t, kStreamOver);
       bool explored;
       const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);  // main.py:92
-      const StepOut o = env_step(b, a, act, x.x2, x.x3);                               // :93
+      const StepOut o = env_step_profile<ENV>(b, a, act, x.x2, x.x3, y.x0, y.x1);      // :93
       const auto key_n = state_key(b, salt, status);                                   // :94
       const bool same = key_eq(key_n, key_s);
       // the row of s: claimed one step ago (in flight since), or now if s opened the episode/launch
@@ -629,7 +643,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
       const bool updated = slot_s >= 0;
       if (updated)
         nq = td_update(&table[slot_s], act, row_get(q, act), o.reward, max_next, o.done != 0, lr,
-                       gamma, retries, td_mode);                                       // :43, :99
+                       gamma, retries, play_only ? (uint32_t)kTdNone : td_mode);       // :43, :99
       if (o.done) {                                                                    // :103
         // the terminal state's row exists in the reference too (looked up at :41)
         if (!same && slot_n < 0 && slot_n != kNoSlot && !x_noclaim)
@@ -649,10 +663,11 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
             log[at] = rec;
           }
         }
-        begin_episode(b, a, seed, id);                                                 // :81
+        begin_episode(b, a, seed, id, (ENV & kEnvResetShaping) != 0);                  // :81
         key_s = state_key(b, salt, status);
         bool made = false;
-        slot_s = probe_find(table, mask, key_s, q, made);
+        q = Row{0.f, 0.f, 0.f, 0.f};
+        slot_s = play_only ? kNoSlot : probe_find(table, mask, key_s, q, made);
         ins_n = ins_n || made;
       } else if (same) {            // invalid move: same state, its row just changed (:100)
         if (updated) row_set(q, act, nq);
@@ -668,7 +683,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
       n_valid += wave_count(o.valid != 0);
       n_explore += wave_count(explored);
       n_insert += wave_count(ins_s) + wave_count(ins_n);
-      n_drop += wave_count(!updated);
+      n_drop += wave_count(!updated && !play_only);
       n_done += wave_count(o.done != 0);
       reward_sum += (double)o.reward;
     }
@@ -925,19 +940,43 @@ __global__ __launch_bounds__(kBlock) void k_rt_fused_rollout(
 // ---------------------------------------------------------------------------------------------
 // table utilities
 // ---------------------------------------------------------------------------------------------
+// Streams the whole table once: every lane reads the first 16 bytes of a slot ({key, q0, q1}; a
+// wave covers 2 KiB of consecutive slots, four slots per lane in flight), occupied slots are
+// compacted per wave with a ballot and a prefix popcount, and ONE atomic add per wave that holds
+// any row reserves its output range (none at all for the empty stretches that make up most of a
+// sparse table).  Non-temporal loads: a scan must not evict the rows the rollout is working on.
+constexpr int kExportUnroll = 4;
 __global__ __launch_bounds__(kBlock) void k_table_export(const q2048_slot* table, u64 cap,
                                                          u64* keys_out, float* q_out, int64_t max_rows,
                                                          int key_words, u64* count) {
   const u64 stride = (u64)gridDim.x * kBlock;
-  for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < cap; i += stride) {
-    const u64 k = table[i].key;
-    if (k == 0ull) continue;
-    const u64 at = atomicAdd(count, 1ull);
-    if (keys_out != nullptr && (int64_t)at < max_rows) {
-      keys_out[at * (u64)key_words] = k;
-      if (key_words == 2) keys_out[at * 2ull + 1ull] = table[i].reserved;
-      reinterpret_cast<float4*>(q_out)[at] =
-          make_float4(table[i].q[0], table[i].q[1], table[i].q[2], table[i].q[3]);
+  const u32x4* t16 = reinterpret_cast<const u32x4*>(table);
+  const u64 lane_lt = (1ull << (threadIdx.x & 63)) - 1ull;
+  for (u64 i0 = (u64)blockIdx.x * kBlock + threadIdx.x; i0 < cap; i0 += kExportUnroll * stride) {
+    u32x4 v[kExportUnroll];
+#pragma unroll
+    for (int k = 0; k < kExportUnroll; ++k) {
+      const u64 i = i0 + (u64)k * stride;
+      v[k] = u32x4{0u, 0u, 0u, 0u};
+      if (i < cap) v[k] = __builtin_nontemporal_load(&t16[2ull * i]);
+    }
+#pragma unroll
+    for (int k = 0; k < kExportUnroll; ++k) {
+      const u64 i = i0 + (u64)k * stride;
+      const bool occ = (v[k].x | v[k].y) != 0u;
+      const u64 bal = __ballot(occ);
+      if (bal == 0ull) continue;                       // wave-uniform
+      u64 base = 0ull;
+      if ((u64)(threadIdx.x & 63) == (u64)__ffsll((long long)bal) - 1ull)
+        base = atomicAdd(count, (u64)__popcll(bal));
+      base = __shfl(base, __ffsll((long long)bal) - 1);
+      const u64 at = base + (u64)__popcll(bal & lane_lt);
+      if (occ && keys_out != nullptr && (int64_t)at < max_rows) {
+        const u32x4 w = __builtin_nontemporal_load(&t16[2ull * i + 1ull]);   // {q2, q3, second key word}
+        keys_out[at * (u64)key_words] = (u64)v[k].x | ((u64)v[k].y << 32);
+        if (key_words == 2) keys_out[at * 2ull + 1ull] = (u64)w.z | ((u64)w.w << 32);
+        reinterpret_cast<u32x4*>(q_out)[at] = u32x4{v[k].z, v[k].w, w.x, w.y};
+      }
     }
   }
 }
@@ -982,7 +1021,8 @@ inline unsigned grid_for(int64_t B) { return (unsigned)((B + kBlock - 1) / kBloc
 inline int launch_status() { return hipGetLastError() == hipSuccess ? Q2048_OK : Q2048_ERR_LAUNCH; }
 inline int check_batch(int64_t B, int n) {
   if (n != 4 && n != 5) return Q2048_ERR_UNSUPPORTED;
-  if (B < 0 || B > ((int64_t)1 << 40)) return Q2048_ERR_SIZE;
+  // one block per 256 envs and HIP caps grid.x at 2^31 - 1 blocks
+  if (B < 0 || B > (int64_t)0x7fffffff * kBlock) return Q2048_ERR_SIZE;
   return Q2048_OK;
 }
 inline int check_table(const void* table, int cap_log2) {
@@ -1001,6 +1041,26 @@ inline int check_table(const void* table, int cap_log2) {
       hipLaunchKernelGGL(kernel<5>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)(stream),    \
                          __VA_ARGS__);                                                            \
   } while (0)
+// launches kernel<4, ENV> or kernel<5, ENV>, ENV = the env profile bits of `flags`
+#define Q2048_LAUNCH_ENV_CASE(kernel, E, n, B, stream, ...)                                       \
+  case E:                                                                                         \
+    if ((n) == 4)                                                                                 \
+      hipLaunchKernelGGL((kernel<4, E>), dim3(grid_for(B)), dim3(kBlock), 0,                      \
+                         (hipStream_t)(stream), __VA_ARGS__);                                     \
+    else                                                                                          \
+      hipLaunchKernelGGL((kernel<5, E>), dim3(grid_for(B)), dim3(kBlock), 0,                      \
+                         (hipStream_t)(stream), __VA_ARGS__);                                     \
+    break;
+#define Q2048_LAUNCH_ENV(kernel, flags, n, B, stream, ...)                                        \
+  switch (env_bits(flags)) {                                                                      \
+    Q2048_LAUNCH_ENV_CASE(kernel, 0, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 1, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 2, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 3, n, B, stream, __VA_ARGS__)                                   \
+  }
+inline int env_bits(uint32_t flags) {
+  return ((flags & Q2048_FLAG_ENV_DQN) ? kEnvDqn : 0) | ((flags & Q2048_FLAG_RESET_SHAPING) ? kEnvResetShaping : 0);
+}
 }  // namespace
 
 extern "C" {
@@ -1040,34 +1100,53 @@ int q2048_env_init(uint8_t* boards, q2048_aux* aux, int64_t B, int n, uint64_t s
   return launch_status();
 }
 
-int q2048_env_reset(uint8_t* boards, q2048_aux* aux, const uint8_t* mask, int64_t B, int n,
-                    uint64_t seed, uint64_t env_id0, void* stream) {
+int q2048_env_reset_ex(uint8_t* boards, q2048_aux* aux, const uint8_t* mask, int64_t B, int n,
+                       uint64_t seed, uint64_t env_id0, uint32_t flags, void* stream) {
   if (int e = check_batch(B, n)) return e;
   if (boards == nullptr || aux == nullptr) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
-  Q2048_LAUNCH(k_env_reset, n, B, stream, boards, aux, mask, B, seed, env_id0);
+  Q2048_LAUNCH(k_env_reset, n, B, stream, boards, aux, mask, B, seed, env_id0, flags);
   return launch_status();
 }
 
+int q2048_env_reset(uint8_t* boards, q2048_aux* aux, const uint8_t* mask, int64_t B, int n,
+                    uint64_t seed, uint64_t env_id0, void* stream) {
+  return q2048_env_reset_ex(boards, aux, mask, B, n, seed, env_id0, 0u, stream);
+}
+
 static int env_step_impl(uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, int n,
-                         uint64_t seed, uint64_t env_id0, uint32_t ctr, float* reward,
+                         uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, float* reward,
                          uint8_t* done, uint8_t* max_log2, uint32_t* status,
-                         const uint32_t* draw_pos, const uint32_t* draw_val, void* stream) {
+                         const uint32_t* draw_pos, const uint32_t* draw_val,
+                         const uint32_t* draw_opos, const uint32_t* draw_oval, int draw_stride,
+                         void* stream) {
   if (int e = check_batch(B, n)) return e;
   if (!boards || !aux || !actions || !reward || !done || !max_log2 || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
-  Q2048_LAUNCH(k_env_step, n, B, stream, boards, aux, actions, B, seed, env_id0, ctr, reward, done,
-               max_log2, status, draw_pos, draw_val);
+  Q2048_LAUNCH_ENV(k_env_step, flags & Q2048_FLAG_ENV_DQN, n, B, stream, boards, aux, actions, B, seed,
+                   env_id0, ctr, reward, done, max_log2, status, draw_pos, draw_val, draw_opos,
+                   draw_oval, draw_stride);
   return launch_status();
 }
 
 int q2048_env_step(uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, int n,
                    uint64_t seed, uint64_t env_id0, uint32_t ctr, float* reward, uint8_t* done,
                    uint8_t* max_log2, uint32_t* status, void* stream) {
-  return env_step_impl(boards, aux, actions, B, n, seed, env_id0, ctr, reward, done, max_log2,
-                       status, nullptr, nullptr, stream);
+  return env_step_impl(boards, aux, actions, B, n, seed, env_id0, ctr, 0u, reward, done, max_log2,
+                       status, nullptr, nullptr, nullptr, nullptr, 1, stream);
+}
+
+int q2048_env_step_ex(uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, int n,
+                      uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags,
+                      const uint32_t* draws4, float* reward, uint8_t* done, uint8_t* max_log2,
+                      uint32_t* status, void* stream) {
+  if (draws4 == nullptr)
+    return env_step_impl(boards, aux, actions, B, n, seed, env_id0, ctr, flags, reward, done, max_log2,
+                         status, nullptr, nullptr, nullptr, nullptr, 1, stream);
+  return env_step_impl(boards, aux, actions, B, n, 0, 0, 0, flags, reward, done, max_log2, status,
+                       draws4, draws4 + 1, draws4 + 2, draws4 + 3, 4, stream);
 }
 
 int q2048_env_step_draws(uint8_t* boards, q2048_aux* aux, const uint8_t* actions,
@@ -1075,8 +1154,8 @@ int q2048_env_step_draws(uint8_t* boards, q2048_aux* aux, const uint8_t* actions
                          float* reward, uint8_t* done, uint8_t* max_log2, uint32_t* status,
                          void* stream) {
   if (!draw_pos || !draw_val) return Q2048_ERR_NULL;
-  return env_step_impl(boards, aux, actions, B, n, 0, 0, 0, reward, done, max_log2, status,
-                       draw_pos, draw_val, stream);
+  return env_step_impl(boards, aux, actions, B, n, 0, 0, 0, 0u, reward, done, max_log2, status,
+                       draw_pos, draw_val, nullptr, nullptr, 1, stream);
 }
 
 static int q_choose_impl(const q2048_slot* table, int cap_log2, const uint8_t* boards, int64_t B,
@@ -1161,9 +1240,9 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
   if (steps < 0 || steps > (1 << 30)) return Q2048_ERR_SIZE;
   if (!(eps >= 0.0 && eps <= 1.0) || !(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
   if (B == 0 || steps == 0) return Q2048_OK;
-  Q2048_LAUNCH(k_fused_rollout, n, B, stream, boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B,
-               (int)steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status, log,
-               log_capacity, reinterpret_cast<u64*>(log_count));
+  Q2048_LAUNCH_ENV(k_fused_rollout, flags, n, B, stream, boards, aux, table,
+                   (u64)((1ull << cap_log2) - 1ull), B, (int)steps, eps, lr, gamma, seed, env_id0, ctr0,
+                   flags, stats_i, stats_f, status, log, log_capacity, reinterpret_cast<u64*>(log_count));
   return launch_status();
 }
 
@@ -1214,6 +1293,7 @@ int q2048_legal_moves(const uint8_t* boards, int64_t B, int n, uint8_t* mask_out
 
 int q2048_encode_onehot(const uint8_t* boards, int64_t B, int dtype, void* out, void* stream) {
   if (int e = check_batch(B, 4)) return e;
+  if (B > (int64_t)0x7fffffff * (kBlock / 64)) return Q2048_ERR_SIZE;   // 64 threads per board
   if (!boards || !out) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(out)) return Q2048_ERR_ALIGN;
   if (dtype != 0 && dtype != 1) return Q2048_ERR_RANGE;
@@ -1316,8 +1396,9 @@ int q2048_table_export(const q2048_slot* table, int cap_log2, uint64_t* keys_out
   if (key_words != 1 && key_words != 2) return Q2048_ERR_SIZE;
   if (q_out != nullptr && !aligned16(q_out)) return Q2048_ERR_ALIGN;
   const u64 cap = 1ull << cap_log2;
-  const u64 blocks = (cap + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_table_export, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0,
+  const u64 blocks = (cap + (u64)kBlock * kExportUnroll - 1) / ((u64)kBlock * kExportUnroll);
+  // 8 blocks of 4 waves on each of the 256 CUs: the whole device streams, no tail
+  hipLaunchKernelGGL(k_table_export, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kBlock), 0,
                      (hipStream_t)stream, table, cap, reinterpret_cast<u64*>(keys_out), q_out,
                      max_rows, key_words, reinterpret_cast<u64*>(count));
   return launch_status();

@@ -80,6 +80,55 @@ def allreduce_stats(stats_i: torch.Tensor, stats_f: torch.Tensor, group=None):
     return stats_i, stats_f
 
 
+class StatsAllReduce:
+    """The statistics all-reduce on a stream of its own: `start` snapshots the two
+    vectors on the caller's stream and hands the copy to a side stream for the SUM all-reduce, so
+    the next rollout launch is not ordered behind the collective; `wait` returns the reduced
+    vectors on the host.  With one process (or CPU tensors, the gloo tests) it degenerates to a
+    copy.  One collective in flight at a time."""
+
+    def __init__(self, device=None, group=None):
+        self.group = group
+        self.device = None if device is None else torch.device(device)
+        on_gpu = self.device is not None and self.device.type == "cuda"
+        self.side = torch.cuda.Stream(self.device) if on_gpu else None
+        self._si = self._sf = None
+        self._done = None
+
+    def start(self, stats_i: torch.Tensor, stats_f: torch.Tensor) -> None:
+        if stats_i.numel() != N.NSTAT_I or stats_f.numel() != N.NSTAT_F:
+            raise ValueError("unexpected statistics vector length")
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if self.side is None:
+            self._si, self._sf = stats_i.clone(), stats_f.clone()
+            if multi:
+                dist.all_reduce(self._si, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self._sf, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        main = torch.cuda.current_stream(self.device)
+        self._si, self._sf = stats_i.clone(), stats_f.clone()      # snapshot, ordered on `main`
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            if multi:
+                dist.all_reduce(self._si, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self._sf, op=dist.ReduceOp.SUM, group=self.group)
+            self._si.record_stream(self.side)
+            self._sf.record_stream(self.side)
+            self._done = torch.cuda.Event()
+            self._done.record(self.side)
+
+    def wait(self):
+        """(stats_i, stats_f) of the last `start`, all-reduced, as host numpy arrays."""
+        if self._si is None:
+            raise RuntimeError("wait() without start()")
+        if self._done is not None:
+            self._done.synchronize()
+            self._done = None
+        si, sf = self._si.cpu().numpy(), self._sf.cpu().numpy()
+        self._si = self._sf = None
+        return si, sf
+
+
 def max_over_ranks(value: float, device=None, group=None) -> float:
     """MAX all-reduce of one float (bench timing: the slowest rank defines the step time)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

@@ -51,12 +51,26 @@ class BatchedGame2048Env:
     step counter), never on B or on how a batch is sharded over GPUs."""
 
     def __init__(self, num_envs: int, board_size: int = 4, device="cuda", seed: int = 0,
-                 env_id0: int = 0):
+                 env_id0: int = 0, profile: str = "shaped", reset_shaping_state: bool = False):
+        """profile  "shaped" = Game2048_env of QLearningBase (the hot path's env);
+                    "nopenalty" = the DQN path's Game2048_env,
+                    Deep_QLearning/environment/Game2048_nopenalty_env.py: reward =
+                    calculate_reward2 (-10 invalid-not-over, else the merge score), done =
+                    game_over, with that file's is_game_over quirks (include/q2048.h,
+                    Q2048_FLAG_ENV_DQN).
+        reset_shaping_state  opt-in fix of a reference bug (Game2048_env.py:187-191 keeps
+                    previous_max and the consecutive-action streak across reset()): resets also
+                    restore them to their constructor values.  Default: the reference's behaviour."""
         self.device = _require_gpu(device)
         if board_size not in (4, 5):
             raise NotImplementedError("board_size must be 4 (the reference) or 5")
         if num_envs <= 0:
             raise ValueError("num_envs must be positive")
+        if profile not in ("shaped", "nopenalty"):
+            raise ValueError("profile must be 'shaped' or 'nopenalty'")
+        self.profile, self.reset_shaping_state = profile, bool(reset_shaping_state)
+        self.env_flags = ((N.FLAG_ENV_DQN if profile == "nopenalty" else 0) |
+                          (N.FLAG_RESET_SHAPING if reset_shaping_state else 0))
         self.num_envs, self.board_size = int(num_envs), int(board_size)
         self.cells = self.board_size * self.board_size
         self.seed, self.env_id0 = int(seed), int(env_id0)
@@ -77,19 +91,19 @@ class BatchedGame2048Env:
         """Game2048_env.reset (:187-191) for the lanes where mask != 0 (all when None)."""
         if mask is not None:
             mask = self._as_u8(mask, "mask")
-        N.check(N.lib().q2048_env_reset(_ptr(self.boards), _ptr(self.aux), _ptr(mask),
-                                        self.num_envs, self.board_size, self.seed, self.env_id0,
-                                        _stream(self.device)), "env_reset")
+        N.check(N.lib().q2048_env_reset_ex(_ptr(self.boards), _ptr(self.aux), _ptr(mask),
+                                           self.num_envs, self.board_size, self.seed, self.env_id0,
+                                           self.env_flags, _stream(self.device)), "env_reset")
         return self.boards
 
     def step(self, actions: torch.Tensor):
         """Game2048_env.step (:97-129): returns (boards, reward[B] f32, done[B] bool,
         max_tile[B] int32 raw tile value, the reference's `info`)."""
         actions = self._as_u8(actions, "actions")
-        N.check(N.lib().q2048_env_step(
+        N.check(N.lib().q2048_env_step_ex(
             _ptr(self.boards), _ptr(self.aux), _ptr(actions), self.num_envs, self.board_size, self.seed,
-            self.env_id0, self.ctr & 0xFFFFFFFF, _ptr(self._reward), _ptr(self._done),
-            _ptr(self._max), _ptr(self.status), _stream(self.device)), "env_step")
+            self.env_id0, self.ctr & 0xFFFFFFFF, self.env_flags, None, _ptr(self._reward),
+            _ptr(self._done), _ptr(self._max), _ptr(self.status), _stream(self.device)), "env_step")
         self.ctr += 1
         max_tile = torch.bitwise_left_shift(torch.ones_like(self._max, dtype=torch.int32),
                                             self._max.to(torch.int32))
@@ -129,7 +143,8 @@ class BatchedGame2048Env:
     def state_dict(self) -> dict:
         """Everything needed to continue this batch bit-exactly (host tensors)."""
         return {"boards": self.boards.cpu(), "aux": self.aux.cpu(), "ctr": self.ctr,
-                "seed": self.seed, "env_id0": self.env_id0, "board_size": self.board_size}
+                "seed": self.seed, "env_id0": self.env_id0, "board_size": self.board_size,
+                "profile": self.profile, "reset_shaping_state": self.reset_shaping_state}
 
     def load_state_dict(self, sd: dict) -> None:
         if (sd["board_size"], tuple(sd["boards"].shape)) != (self.board_size, tuple(self.boards.shape)):
@@ -137,6 +152,9 @@ class BatchedGame2048Env:
         self.boards.copy_(sd["boards"])
         self.aux.copy_(sd["aux"])
         self.ctr, self.seed, self.env_id0 = int(sd["ctr"]), int(sd["seed"]), int(sd["env_id0"])
+        if (sd.get("profile", "shaped"), sd.get("reset_shaping_state", False)) != (
+                self.profile, self.reset_shaping_state):
+            raise ValueError("checkpoint was taken with another env profile")
 
     # -- helpers --------------------------------------------------------------------------
     def aux_fields(self) -> dict:

@@ -1,0 +1,110 @@
+"""Single-node rank launcher: one fresh process per GPU.
+
+`python bench.py --gpus N` (and train.py) must work when nothing has set up a process group: the
+parent then starts N children of the same script, each with the torchrun environment
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relays rank 0's stdout and returns
+the worst exit code.  The reference has no distributed code at all, so there is nothing
+it mirrors; the contract is the one `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N` gives a script.
+
+Two rules of the GPU pool shape it:
+  * a process that has initialised the GPU must never exec another program, so the parent calls
+    this BEFORE anything touches HIP (importing torch is fine, `torch.cuda.is_available()` is
+    not), and children are brand-new interpreters, never re-executions of the parent;
+  * processes are stopped by their exact PID, never by pattern.
+
+This module imports nothing from the package (no torch, no ctypes): it is safe to import first.
+"""
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+import threading
+import time
+
+ENV_KEYS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+
+
+def inside_a_launch(environ=None) -> bool:
+    """True when this process already is a rank of a job (torchrun or `launch_ranks`)."""
+    environ = os.environ if environ is None else environ
+    return "WORLD_SIZE" in environ and "RANK" in environ
+
+
+def free_port(addr: str = "127.0.0.1") -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind((addr, 0))
+        return int(s.getsockname()[1])
+
+
+def rank_env(rank: int, world_size: int, master_addr: str, master_port: int, base=None) -> dict:
+    """The environment of one rank (one node: LOCAL_RANK == RANK)."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world_size),
+                "LOCAL_WORLD_SIZE": str(world_size), "MASTER_ADDR": master_addr,
+                "MASTER_PORT": str(master_port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+    return env
+
+
+def launch_ranks(argv, nproc: int, master_addr: str = "127.0.0.1", master_port: int | None = None,
+                 timeout: float | None = None, stdout=None, env=None, poll_s: float = 0.05,
+                 line_filter=None) -> int:
+    """Runs `argv` (a full command line, e.g. [sys.executable, "bench.py", "--gpus", "2"]) as
+    `nproc` ranks and waits for them.
+
+    Rank 0's stdout is relayed line by line to `stdout` (default: this process's stdout) -- the
+    one JSON line of bench.py; the other ranks' stdout goes to this process's stderr, as does
+    every rank's stderr.  `line_filter(line) -> bool` selects which of rank 0's lines are relayed
+    (the rest go to stderr: gloo, for one, announces its connections on stdout).  When a rank exits non-zero, or `timeout` seconds pass, the remaining
+    ranks are terminated (SIGTERM to their PIDs, SIGKILL after 5 s) and the result is non-zero.
+    Returns 0 iff every rank exited 0."""
+    if nproc < 1:
+        raise ValueError("nproc must be >= 1")
+    out = sys.stdout if stdout is None else stdout
+    port = free_port(master_addr) if master_port is None else int(master_port)
+    procs = []
+    for r in range(nproc):
+        procs.append(subprocess.Popen(
+            list(argv), env=rank_env(r, nproc, master_addr, port, env),
+            stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+
+    def relay():
+        for line in procs[0].stdout:
+            dst = out if line_filter is None or line_filter(line) else sys.stderr
+            dst.write(line)
+            dst.flush()
+
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    deadline = None if timeout is None else time.monotonic() + timeout
+    worst, failed = 0, False
+    while True:
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes):
+            failed = True
+            worst = next(c for c in codes if c not in (None, 0))
+            break
+        if all(c == 0 for c in codes):
+            break
+        if deadline is not None and time.monotonic() > deadline:
+            failed, worst = True, 124
+            break
+        time.sleep(poll_s)
+    if failed:
+        for p in procs:                       # exactly the PIDs started above
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    pump.join(timeout=5.0)
+    if failed:
+        return worst if worst > 0 else 1      # a signal's negative code is still a failure
+    return 0

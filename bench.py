@@ -5,29 +5,44 @@
 
 One "step" = one pass of the hot path (choose -> env.step -> TD update -> reset-on-done,
 Agent/main.py:91-101) over the whole batch: 1,048,576 boards per GPU (BASELINE configs[2] at
-N = 1; configs[3] = 8 x 1,048,576 at N = 8, weak scaling).  Boards, aux records and the hash
-Q-table are resident in HBM before the timed region; the timed region is exactly K steps
-(ceil(K / steps_per_launch) launches of the fused kernel) bracketed by barrier + synchronize,
-and the reported time is the MAX over ranks.  Rank 0 prints ONE JSON line.
+N = 1; configs[3] = 8 x 1,048,576 at N = 8, weak scaling).
+
+With N > 1 and no process group in the environment the script starts its own N ranks (one fresh
+child process per GPU, before anything in the parent touches the GPU) and relays rank 0's line;
+under `python -m torch.distributed.run --nproc-per-node N` it joins the group it is given.
+
+Protocol, per rank:
+  1. input synthesis, untimed: `--prep-steps` steps of uniformly random play with no learner
+     (Q2048_FLAG_PLAY_ONLY, eps = 1), so that boards and episode phases are the stationary
+     mid-game mix and not 1 M boards five moves from reset;
+  2. W warm-up steps of the real loop (table warm, RCCL initialised), untimed;
+  3. the K-step region, timed `--repeats` times back to back on the same run (each region =
+     ceil(K / steps_per_launch) launches + the statistics all-reduce, bracketed by barrier +
+     synchronize; MAX over ranks): the MEDIAN region is the one reported.  Every region must
+     finish episodes (`stats.episodes > 0`), or the reset / terminal-row path was not measured.
+Boards, aux records and the hash Q-table are resident in HBM throughout.  Rank 0 prints ONE
+JSON line.
 
 Extra objects on the line:
   roofline      HBM roofline of the dominant kernel (k_fused_rollout): algorithmic bytes per
                 launch (122 B per env-step) / average launch duration measured
-                with HIP events on the launching stream, against the 8 TB/s HBM3E peak.
+                with HIP events on the launching stream, against the 8 TB/s HBM3E peak; `traffic`
+                only when the committed PMC passes were taken with this run's configuration.
   cpu_baseline  the CPU oracle (a C port of the reference loop, oracle/) timed on this host's
-                cores on a bounded sample of the same workload (rank 0, N = 1 only).
+                cores on a bounded sample of the same workload (rank 0, N = 1 only): all cores
+                and one thread, with the CPU model.
+  companions    the same protocol at SURVEY 8(d)'s 2^28-slot table and at eps = 0.01 (N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import importlib
+import importlib.util
 import json
 import os
+import statistics
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -41,13 +56,17 @@ ALGO_BYTES_FUSED_5X5 = 156
 ALGO_BYTES_ROW_TUPLE = 64 + 8 * 16 + 4 * 4 + 6
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
+PMC_TRAFFIC_FILE = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=256)
     p.add_argument("--warmup", type=int, default=64)
+    p.add_argument("--repeats", type=int, default=5, help="timed K-step regions; the median is reported")
+    p.add_argument("--prep-steps", type=int, default=1024,
+                   help="input synthesis: untimed steps of random play without a learner (>= 64)")
     p.add_argument("--boards-per-gpu", type=int, default=1 << 20)
     p.add_argument("--board-size", type=int, default=4, help="4 (BASELINE configs[2]/[3]) or 5 (configs[4])")
     p.add_argument("--agent", choices=["hash", "row-tuple"], default="hash",
@@ -67,34 +86,53 @@ def parse_args():
     p.add_argument("--strict-td", action="store_true",
                    help="TD write by compare-and-swap loop (Q2048_FLAG_TD_CAS) instead of one store")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 = skip")
-    return p.parse_args()
+    p.add_argument("--no-companions", action="store_true",
+                   help="skip the 2^28-slot and eps = 0.01 companion runs (N = 1 only anyway)")
+    return p.parse_args(argv)
 
 
-def pmc_traffic_per_env_step():
-    """HBM-side bytes per env-step from the committed rocprofv3 PMC passes (profiles/), or None.
-    Collected in separate --pmc passes on the same bench command (tools/pmc_session.sh)."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+def load_launcher():
+    """The rank launcher, loaded by path so that the parent imports neither torch nor the package."""
+    spec = importlib.util.spec_from_file_location(
+        "q2048_launch", os.path.join(REPO, "2048_q-learning_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def committed_pmc_traffic(cfg: dict):
+    """(bytes per env-step, source, None) when the committed rocprofv3 PMC passes (profiles/) were
+    taken with this run's configuration, else (None, None, the configuration they were taken with)."""
     try:
-        with open(path) as fh:
-            return json.load(fh)
+        with open(PMC_TRAFFIC_FILE) as fh:
+            pmc = json.load(fh)
     except (OSError, ValueError):
-        return None
+        return None, None, None
+    have = pmc.get("config", {})
+    if all(have.get(k) == v for k, v in cfg.items()):
+        return pmc["bytes_per_env_step"], pmc["source"], None
+    return None, None, have
 
 
-def table_capacity_log2(pkg, boards: int, total_steps: int, device) -> int:
-    """Every step may create a row: load <= 0.5 at the end of the run, and beyond that half of
-    the device's free memory (2^32 slots x 32 B = 128 GiB of the 288 GB): a table that large
-    spans the whole memory system, which is where scattered writes run fastest."""
-    return pkg.auto_capacity_log2(boards * max(total_steps, 1), device, max_log2=32)
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(args, seconds: float) -> dict:
-    """Times the CPU oracle (kind 'port') on a bounded sample of the same workload."""
+    """Times the CPU oracle (kind 'port') on a bounded sample of the same workload: one thread,
+    a quarter of the cores and all usable cores, each with a private Q-table per thread."""
     from oracle import oracle as O
 
     O.lib()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    best = None
+    runs = {}
     for T in sorted({1, max(1, cores // 4), cores}):
         B, steps = 16384 * T, 24
         envs = O.envs_init(B, 4, args.seed, 0)
@@ -112,27 +150,123 @@ def cpu_baseline(args, seconds: float) -> dict:
             dt = time.perf_counter() - t0
             if dt > budget or ctr > 56:
                 break
-        rate = done / dt
-        if best is None or rate > best[0]:
-            best = (rate, T, B, ctr - 8, dt)
+        runs[T] = (done / dt, B, ctr - 8, dt)
         del agents, envs
-    rate, T, B, steps, dt = best
+    T = max(runs, key=lambda t: runs[t][0])
+    rate, B, steps, dt = runs[T]
     return {"value": rate, "unit": "env-steps/s", "cores": T, "kind": "port",
             "sample": f"oracle/q2048_oracle.c orc_rollout_mt: {B} boards x {steps} steps, "
                       f"{T} thread(s) with one private Q-table each, {dt:.1f} s "
                       f"(host has {cores} usable cores)",
+            "single_thread": {"value": runs[1][0], "cores": 1,
+                              "sample": f"{runs[1][1]} boards x {runs[1][2]} steps, {runs[1][3]:.1f} s"},
+            "by_threads": {str(t): r[0] for t, r in sorted(runs.items())},
+            "cpu_model": cpu_model(), "usable_cores": cores,
             "reference_python_1core_survey_container": 11144.0}
 
 
-def main():
-    args = parse_args()
-    if args.steps < 1 or args.warmup < 0:
-        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
+def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, steps, warmup, repeats,
+            S, reducer):
+    """The protocol of the module docstring for one configuration.  Returns a dict of raw
+    measurements (region times are MAX over ranks)."""
+    env = pkg.BatchedGame2048Env(shard.num_envs, board_size=args.board_size, seed=args.seed,
+                                 env_id0=shard.env_id0, device=dev)
+    if args.agent == "row-tuple":
+        agent = pkg.BatchedRowTupleAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
+                                         exploration_rate=eps, seed=args.seed,
+                                         env_id0=shard.env_id0, device=dev)
+        synth = pkg.BatchedQLearningAgent(1000, exploration_rate=1.0, capacity_log2=4, seed=args.seed,
+                                          env_id0=shard.env_id0, device=dev, board_size=4,
+                                          placement="plain")
+    else:
+        agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
+                                          exploration_rate=eps, capacity_log2=cap_log2,
+                                          seed=args.seed, env_id0=shard.env_id0, device=dev,
+                                          strict_td=args.strict_td, board_size=args.board_size,
+                                          placement=placement)
+        synth = agent
+
+    def run(steps_):
+        launches, left = 0, steps_
+        while left > 0:
+            k = min(S, left)
+            agent.fused_rollout(env, k)
+            left -= k
+            launches += 1
+        return launches
+
+    # 1. input synthesis: random play, no learner, nothing of the table touched
+    keep_eps, synth.epsilon = synth.epsilon, 1.0
+    left = args.prep_steps
+    while left > 0:
+        k = min(256, left)
+        synth.fused_rollout(env, k, play_only=True)
+        left -= k
+    synth.epsilon = keep_eps
+    synth.ctr = agent.ctr = env.ctr
+    synth.stats(reset=True)
+    prep_episodes_per_env = float(env.aux_fields()["episode"].mean())
+
+    # 2. warm-up of the real loop
+    run(warmup)
+    reducer.start(agent.stats_i, agent.stats_f)      # untimed: RCCL builds its rings lazily
+    reducer.wait()
+
+    # 3. timed regions
+    regions = []
+    for _ in range(repeats):
+        agent.stats(reset=True)
+        torch.cuda.synchronize(dev)
+        pkg.dist.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        launches = run(steps)                        # exactly K steps
+        ev1.record()
+        reducer.start(agent.stats_i, agent.stats_f)  # the path's only collective, on its own stream
+        si, sf = reducer.wait()
+        torch.cuda.synchronize(dev)
+        pkg.dist.barrier()
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        st = pkg.stats_dict(si, sf)                  # all-reduced: whole-job numbers
+        total = shard.total_envs * steps
+        assert st["steps"] == total, (st["steps"], total)
+        assert st["episodes"] > 0, "no episode finished inside a timed region: reset path unmeasured"
+        regions.append({"wall_s": pkg.dist.max_over_ranks(wall, device=dev),
+                        "kernel_ms": pkg.dist.max_over_ranks(ev0.elapsed_time(ev1), device=dev),
+                        "launches": launches, "stats": st})
+    table_rows = agent.table_size() if args.agent == "hash" else None
+    status = agent.check_status()
+    placement_report = getattr(agent, "placement", None)
+    del agent, synth, env
+    torch.cuda.empty_cache()
+    return {"regions": regions, "table_rows": table_rows, "status": status,
+            "placement": placement_report, "prep_episodes_per_env": prep_episodes_per_env}
+
+
+def summarise(m, shard, steps, algo_bytes):
+    """Median region -> value, ms_per_step, roofline numbers."""
+    walls = [r["wall_s"] for r in m["regions"]]
+    med = statistics.median_low(walls)
+    reg = m["regions"][walls.index(med)]
+    launches = reg["launches"]
+    avg_launch_s = sum(r["kernel_ms"] for r in m["regions"]) / 1e3 / (launches * len(m["regions"]))
+    achieved = algo_bytes * shard.num_envs * (steps / launches) / avg_launch_s / 1e9
+    return {"value": shard.total_envs * steps / med, "ms_per_step": med * 1e3 / steps,
+            "region_ms": [round(w * 1e3, 4) for w in walls], "median_region": reg,
+            "avg_launch_s": avg_launch_s, "launches": launches, "achieved_gbs": achieved}
+
+
+def run_rank(args):
+    import numpy as np  # noqa: F401  (the package needs it; fail early)
+    import torch
+
     pkg = importlib.import_module("2048_q-learning_amd")
     rank, local_rank, world = pkg.dist.init_process_group()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun "
-                         f"--nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())  # 1 rank = 1 GPU on a node
@@ -141,82 +275,56 @@ def main():
     B = args.boards_per_gpu
     shard = pkg.weak_shard(B, world, rank)
     S = max(1, min(args.steps_per_launch, args.steps))
-    cap_log2 = args.cap_log2 or table_capacity_log2(pkg, B, args.steps + args.warmup, dev)
-
+    learn_steps = args.warmup + args.repeats * args.steps
+    # every step may create a row: load <= 0.5 at the end of the run, and beyond that half of the
+    # device's free memory (a table that spans the memory system: DESIGN.md 4 "table placement")
+    cap_log2 = args.cap_log2 or pkg.auto_capacity_log2(B * max(learn_steps, 1), dev, max_log2=32)
     algo_bytes = ALGO_BYTES_FUSED_4X4 if args.board_size == 4 else ALGO_BYTES_FUSED_5X5
     if args.agent == "row-tuple":
         algo_bytes = ALGO_BYTES_ROW_TUPLE
-    env = pkg.BatchedGame2048Env(shard.num_envs, board_size=args.board_size, seed=args.seed,
-                                 env_id0=shard.env_id0, device=dev)
-    if args.agent == "row-tuple":
-        agent = pkg.BatchedRowTupleAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
-                                         exploration_rate=args.eps, seed=args.seed,
-                                         env_id0=shard.env_id0, device=dev)
-    else:
-        agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
-                                          exploration_rate=args.eps, capacity_log2=cap_log2,
-                                          seed=args.seed, env_id0=shard.env_id0, device=dev,
-                                          strict_td=args.strict_td, board_size=args.board_size,
-                                          placement=args.placement)
+    reducer = pkg.StatsAllReduce(dev)
 
-    def run(steps):
-        launches = 0
-        left = steps
-        while left > 0:
-            k = min(S, left)
-            agent.fused_rollout(env, k)
-            left -= k
-            launches += 1
-        return launches
+    m = measure(pkg, torch, args, dev, shard, world, eps=args.eps, cap_log2=cap_log2,
+                placement=args.placement, steps=args.steps, warmup=args.warmup,
+                repeats=args.repeats, S=S, reducer=reducer)
+    s = summarise(m, shard, args.steps, algo_bytes)
+    st = s["median_region"]["stats"]
 
-    run(args.warmup)                       # mid-game boards, warm table (untimed)
-    pkg.dist.allreduce_stats(agent.stats_i, agent.stats_f)   # untimed: RCCL builds its rings lazily
-    agent.stats(reset=True)
-    torch.cuda.synchronize(dev)
-    pkg.dist.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    launches = run(args.steps)             # exactly K steps
-    ev1.record()
-    pkg.dist.allreduce_stats(agent.stats_i, agent.stats_f)   # the path's only collective
-    torch.cuda.synchronize(dev)
-    pkg.dist.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)      # HIP events on the launching stream
-    wall_max = pkg.dist.max_over_ranks(wall, device=dev)
-    kernel_ms_max = pkg.dist.max_over_ranks(kernel_ms, device=dev)
-
-    st = agent.stats()                     # all-reduced: whole-job numbers
-    table_rows = agent.table_size() if args.agent == "hash" else None   # this rank's replica, after W + K steps
-    status = agent.check_status()
-    total_env_steps = shard.total_envs * args.steps
-    assert st["steps"] == total_env_steps, (st["steps"], total_env_steps)
-    value = total_env_steps / wall_max
-
-    # roofline of the dominant kernel, per launch, on this rank
-    avg_launch_s = (kernel_ms_max / 1e3) / launches
-    algo_bytes_per_launch = algo_bytes * shard.num_envs * (args.steps / launches)
-    achieved = algo_bytes_per_launch / avg_launch_s / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_rt_fused_rollout" if args.agent == "row-tuple" else "k_fused_rollout", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-                "traffic": None,  # filled below from the committed PMC passes
+    kernel = "k_rt_fused_rollout" if args.agent == "row-tuple" else "k_fused_rollout"
+    roofline = {"bound": "hbm", "kernel": kernel, "achieved": s["achieved_gbs"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s["achieved_gbs"] / HBM_PEAK_GBS,
+                "frac_of_measured_copy_ceiling": s["achieved_gbs"] / HBM_COPY_CEILING_GBS,
+                "traffic": None,
                 "algorithmic_bytes_per_env_step": algo_bytes,
-                "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                "avg_launch_ms": s["avg_launch_s"] * 1e3, "launches": s["launches"],
                 "note": f"register-resident, K={S} env steps per launch: boards/aux cross HBM once "
                         f"per launch, the figure counts them once per step (SURVEY 8(d))"}
+    if args.agent == "hash":
+        # what a step has to move at the least, from this run's own statistics: the board + aux
+        # image once per launch, one 32-B row read for every move that reaches another state, the
+        # 4-B Q write, the 8-B key of every new row
+        moved = st["valid_moves"] / max(st["steps"], 1)
+        new_rows = st["inserts"] / max(st["steps"], 1)
+        cells = args.board_size ** 2
+        phys = (2 * (cells + 16)) / S + 32.0 * moved + 4.0 + (8.0 if args.board_size == 4 else 16.0) * new_rows
+        per_launch_phys = phys * shard.num_envs * (args.steps / s["launches"])
+        roofline["physical_minimum"] = {
+            "bytes_per_env_step": phys, "achieved": per_launch_phys / s["avg_launch_s"] / 1e9,
+            "frac": per_launch_phys / s["avg_launch_s"] / 1e9 / HBM_PEAK_GBS,
+            "note": "useful bytes only (no line granularity); the memory system moves whole 64-B lines"}
+        cfg = {"boards": shard.num_envs, "steps_per_launch": S, "cap_log2": cap_log2,
+               "board_size": args.board_size, "eps": args.eps, "strict_td": bool(args.strict_td)}
+        per_step, source, other = committed_pmc_traffic(cfg)
+        if per_step is not None:
+            roofline["traffic"] = per_step * shard.num_envs * (args.steps / s["launches"])
+            roofline["traffic_bytes_per_env_step"] = per_step
+            roofline["traffic_source"] = source
+        elif other is not None:
+            roofline["traffic_profile_config"] = other   # the committed passes are for another run
 
-    pmc = pmc_traffic_per_env_step() if (args.board_size == 4 and args.agent == "hash") else None
-    if pmc is not None:
-        roofline["traffic"] = pmc["bytes_per_env_step"] * shard.num_envs * (args.steps / launches)
-        roofline["traffic_source"] = pmc["source"]
-        roofline["traffic_bytes_per_env_step"] = pmc["bytes_per_env_step"]
     out = {
-        "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_max * 1e3 / args.steps,
+        "metric": "env_steps_per_sec", "value": s["value"], "unit": "env-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": s["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": f"{B} parallel {args.board_size}x{args.board_size} boards per GPU (uint8 "
@@ -228,18 +336,52 @@ def main():
                    "table_bytes_per_gpu": (1 << cap_log2) * 32, "epsilon": args.eps,
                    "alpha": args.alpha, "gamma": args.gamma, "seed": args.seed,
                    "td_write": "compare-and-swap" if args.strict_td else "store (last writer wins)",
-                   "table_placement": getattr(agent, "placement", None),
-                   "parallelism": f"env-batch x{world}, RCCL all-reduce of statistics only"},
+                   "table_placement": m["placement"],
+                   "prep_steps": args.prep_steps, "repeats": args.repeats,
+                   "timing": "median of `repeats` K-step regions after `prep_steps` of random play "
+                             "and `warmup` learning steps",
+                   "parallelism": f"env-batch x{world}, RCCL all-reduce of statistics only "
+                                  f"(side stream)"},
+        "region_ms": s["region_ms"],
         "roofline": roofline,
         "stats": {"episodes": st["episodes"], "mean_return": st["mean_return"],
                   "mean_score": st["mean_score"], "valid_move_frac": st["valid_moves"] / max(st["steps"], 1),
-                  "table_inserts": st["inserts"], "drops": st["drops"],
-                  "table_rows_per_gpu": table_rows, "claim_timeouts": pkg._native.claim_timeouts(),
-                  "table_load_factor": None if table_rows is None else table_rows / float(1 << cap_log2),
-                  "cas_retries": st["cas_retries"], "status": status,
+                  "table_inserts": st["inserts"], "inserts_per_step": st["inserts"] / max(st["steps"], 1),
+                  "drops": st["drops"],
+                  "table_rows_per_gpu": m["table_rows"], "claim_timeouts": pkg._native.claim_timeouts(),
+                  "table_load_factor": None if m["table_rows"] is None else m["table_rows"] / float(1 << cap_log2),
+                  "cas_retries": st["cas_retries"], "status": m["status"],
+                  "episodes_per_env_before_timing": m["prep_episodes_per_env"],
                   "max_tile_hist": {str(k): v for k, v in st["max_tile_hist"].items()}},
-        "kernel_ms_total": kernel_ms_max,
+        "kernel_ms_total": sum(r["kernel_ms"] for r in m["regions"]),
     }
+
+    if world == 1 and args.agent == "hash" and not args.no_companions:
+        # the 2^28-slot table the survey specified and the exploit-heavy eps = 0.01
+        # run; each sized so that its table ends below load 0.5
+        comps = []
+        for name, c_eps, c_cap in (("capacity 2^28 (SURVEY 8(d))", args.eps, 28),
+                                   ("epsilon 0.01 (argmax path)", 0.01, cap_log2)):
+            budget = int(0.5 * (1 << c_cap) / (0.75 * B))          # learning steps the table can take
+            c_rep = 3
+            c_steps = max(1, min(args.steps, budget // (c_rep + 1)))
+            c_warm = max(1, min(args.warmup, budget - c_rep * c_steps))
+            c_S = max(1, min(S, c_steps))
+            cm = measure(pkg, torch, args, dev, shard, world, eps=c_eps, cap_log2=c_cap,
+                         placement="plain" if c_cap < 31 else args.placement, steps=c_steps,
+                         warmup=c_warm, repeats=c_rep, S=c_S, reducer=reducer)
+            cs = summarise(cm, shard, c_steps, algo_bytes)
+            cst = cs["median_region"]["stats"]
+            comps.append({"name": name, "epsilon": c_eps, "table_capacity_log2": c_cap,
+                          "steps": c_steps, "warmup": c_warm, "repeats": c_rep,
+                          "steps_per_launch": c_S, "value": cs["value"],
+                          "ms_per_step": cs["ms_per_step"], "region_ms": cs["region_ms"],
+                          "roofline_frac": cs["achieved_gbs"] / HBM_PEAK_GBS,
+                          "inserts_per_step": cst["inserts"] / max(cst["steps"], 1),
+                          "episodes": cst["episodes"],
+                          "table_load_factor": cm["table_rows"] / float(1 << c_cap)})
+        out["companions"] = comps
+
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
     elif rank == 0:
@@ -248,6 +390,21 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.steps < 1 or args.warmup < 0 or args.repeats < 1 or args.gpus < 1:
+        raise SystemExit("--steps, --repeats, --gpus must be >= 1 and --warmup >= 0")
+    args.prep_steps = max(64, args.prep_steps)      # at least 64 steps of synthesis
+    launcher = load_launcher()
+    if args.gpus > 1 and not launcher.inside_a_launch():
+        # the parent of the job: it has made no GPU call, starts one fresh process per rank,
+        # relays rank 0's JSON line and exits with the ranks' worst code
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+        raise SystemExit(launcher.launch_ranks(cmd, args.gpus,
+                                               line_filter=lambda ln: ln.lstrip().startswith("{")))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define Q2048_ABI_VERSION 1
+#define Q2048_ABI_VERSION 2 /* 2: env profiles (_ex entry points), PLAY_ONLY, device-side deterministic step */
 
 /* return codes */
 #define Q2048_OK 0
@@ -62,6 +62,25 @@ extern "C" {
 #define Q2048_FLAG_TD_CAS 4u      /* TD update by a compare-and-swap loop: concurrent updates of one
                                      (s, a) serialise instead of "last writer wins"; identical to
                                      the default whenever no two lanes share (s, a) */
+
+#define Q2048_FLAG_ENV_DQN 8u      /* env step = the DQN path's env instead of Game2048_env.step:
+                                     Deep_QLearning/environment/Game2048_nopenalty_env.py:106-138 --
+                                     reward = calculate_reward2 (-10 for an invalid move while the game
+                                     is not over, else the move's merge score; :122-138), done =
+                                     game_over (:117-118), is_game_over evaluated on the board from
+                                     BEFORE the move and, on a full board, replacing the result by its
+                                     own first legal move (:68-78); the caller's write-back
+                                     `env.game.board = next_state` (main_dir/mainDQL_CNN_step2.py:237)
+                                     is part of the step.  No shaping state is read or written. */
+#define Q2048_FLAG_RESET_SHAPING 16u /* a reset also restores previous_max and the consecutive-action
+                                     state to their constructor values (Game2048_env.py:87,92-95).
+                                     NOT the reference's behaviour (its reset, :187-191, keeps them:
+                                     a lane ended by the >100-repeats rule ends again on its next
+                                     repeat); opt-in fix of SURVEY 7.8 */
+#define Q2048_FLAG_PLAY_ONLY 32u   /* fused rollout without a learner: the table is neither read nor
+                                     written, every Q row reads as zeros.  With eps = 1 this is
+                                     uniformly random play (input synthesis for benchmarks, the
+                                     arithmetic floor of the kernel) */
 
 /* per-env state, Game2048_env.__init__ (Game2048_env.py:81-95) + episode bookkeeping */
 typedef struct q2048_aux {
@@ -134,6 +153,10 @@ int q2048_env_init(uint8_t *boards, q2048_aux *aux, int64_t B, int n, uint64_t s
 int q2048_env_reset(uint8_t *boards, q2048_aux *aux, const uint8_t *mask, int64_t B, int n,
                     uint64_t seed, uint64_t env_id0, void *stream);
 
+/* q2048_env_reset with flags (Q2048_FLAG_RESET_SHAPING; other bits ignored). */
+int q2048_env_reset_ex(uint8_t *boards, q2048_aux *aux, const uint8_t *mask, int64_t B, int n,
+                       uint64_t seed, uint64_t env_id0, uint32_t flags, void *stream);
+
 /* Game2048_env.step(action) (Game2048_env.py:97-129) for B envs: move (:51-63), game-over
  * probe (:65-75), shaped reward (:136-184, :197-205), stall rule (:110-127).
  * Outputs per lane: reward (float32 of the reference's float), done, max tile as log2
@@ -151,6 +174,17 @@ int q2048_env_step_draws(uint8_t *boards, q2048_aux *aux, const uint8_t *actions
                          const uint32_t *draw_pos, const uint32_t *draw_val, int64_t B, int n,
                          float *reward, uint8_t *done, uint8_t *max_log2, uint32_t *status,
                          void *stream);
+
+/* q2048_env_step with an env profile: flags = Q2048_FLAG_ENV_DQN selects the DQN path's step
+ * (Game2048_nopenalty_env.py:106-138, see the flag); 0 = q2048_env_step.  draws4 = NULL: draws
+ * derived from (seed, id, ctr) -- the chosen move's spawn from words 2, 3 of stream 0 as always,
+ * the spawn inside is_game_over's move from words 0, 1 of stream 2.  draws4 = uint32[B][4]:
+ * injected draws {pos, val, over_pos, over_val} per env (parity with the reference; seed /
+ * env_id0 / ctr are then unused). */
+int q2048_env_step_ex(uint8_t *boards, q2048_aux *aux, const uint8_t *actions, int64_t B, int n,
+                      uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags,
+                      const uint32_t *draws4, float *reward, uint8_t *done, uint8_t *max_log2,
+                      uint32_t *status, void *stream);
 
 /* QLearningAgent.choose_action(state) (Agent/main.py:34-38) for B states: epsilon test and
  * random action from the step draws, else first-maximum argmax of the row (zeros if absent;
@@ -188,7 +222,8 @@ int q2048_q_lookup(const q2048_slot *table, int cap_log2, const uint8_t *boards,
  * launch: choose -> step -> update -> accumulate -> (on done) statistics and reset.  Boards,
  * aux and the Q row of the current state stay in registers between steps.  Step t uses the
  * draws of counter ctr0 + t.  Bit-identical to calling q_choose / env_step / q_update /
- * env_reset(done) `steps` times whenever no two lanes share a state. */
+ * env_reset(done) `steps` times whenever no two lanes share a state.
+ * flags: Q2048_FLAG_INDEPENDENT, _TD_CAS, _ENV_DQN, _RESET_SHAPING, _PLAY_ONLY. */
 int q2048_fused_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2,
                         int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
                         uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,

@@ -17,7 +17,8 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 MAXCELLS = 32
 NO_ACTION = -1
-STREAM_STEP, STREAM_RESET = 0, 1
+STREAM_STEP, STREAM_RESET, STREAM_OVER = 0, 1, 2
+ENV_DQN, ENV_RESET_SHAPING = 1, 2     # env_flags of rollout()
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE = range(7)
 ST_HIST0, ST_NI = 8, 32
 SF_RETURN, SF_RETURN_SQ, SF_REWARD, SF_NF = 0, 1, 2, 4
@@ -114,6 +115,11 @@ def lib() -> C.CDLL:
         "orc_rt_update": (None, [vp, u8p, C.c_int, C.c_float, u8p, C.c_int, C.c_double, C.c_double]),
         "orc_rt_rollout": (None, [vp, C.c_int64, vp, C.c_int64, C.c_double, C.c_double, C.c_double,
                                   C.c_uint64, C.c_uint64, C.c_uint32, i64p, f64p]),
+        "orc_env_step_dqn": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f64p,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "orc_env_reset_shaping": (None, [vp]),
+        "orc_rollout_ex": (None, [vp, C.c_int64, vp, C.c_int64, C.c_uint64, C.c_uint64,
+                                  C.c_uint32, u8p, i64p, f64p, u8p, f64p, u8p, C.c_int]),
         "orc_sizeof_env": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -238,6 +244,16 @@ class Env:
             raise ValueError(f"action {action} outside 0..3")
         return self.board, r.value, bool(d.value), m.value, bool(v)
 
+    def step_dqn(self, action: int, draw_pos: int = 0, draw_val: int = 0, over_pos: int = 0,
+                 over_val: int = 0):
+        """Game2048_nopenalty_env.step (+ the caller's board write-back): see orc_env_step_dqn."""
+        r, d, m = C.c_double(0), C.c_int(0), C.c_int(0)
+        v = lib().orc_env_step_dqn(self.rec.ctypes.data, int(action), int(draw_pos), int(draw_val),
+                                   int(over_pos), int(over_val), C.byref(r), C.byref(d), C.byref(m))
+        if v < 0:
+            raise ValueError(f"action {action} outside 0..3")
+        return self.board, r.value, bool(d.value), m.value, bool(v)
+
     def calculate_reward(self, score, valid, game_over, max_log2) -> float:
         return lib().orc_calculate_reward(self.rec.ctypes.data, int(score), int(valid),
                                           int(game_over), int(max_log2))
@@ -321,8 +337,10 @@ def envs_init(B: int, n: int = 4, seed: int = 0, env_id0: int = 0) -> np.ndarray
 
 def rollout(envs: np.ndarray, agent: Agent | None, steps: int, seed: int = 0,
             env_id0: int = 0, ctr0: int = 0, actions: np.ndarray | None = None,
-            record: bool = False):
-    """Runs `steps` lockstep steps in place.  Returns (stats_i, stats_f[, acts, rew, done])."""
+            record: bool = False, env_flags: int = 0):
+    """Runs `steps` lockstep steps in place.  Returns (stats_i, stats_f[, acts, rew, done]).
+    env_flags: ENV_DQN = the DQN path's env (calculate_reward2, done = game_over),
+    ENV_RESET_SHAPING = resets also restore the shaping state."""
     B = len(envs)
     si = np.zeros(ST_NI, dtype=np.int64)
     sf = np.zeros(SF_NF, dtype=np.float64)
@@ -333,10 +351,10 @@ def rollout(envs: np.ndarray, agent: Agent | None, steps: int, seed: int = 0,
         dn = np.zeros((steps, B), dtype=np.uint8)
     if actions is not None:
         actions = np.ascontiguousarray(actions, dtype=np.uint8).reshape(steps, B)
-    lib().orc_rollout(envs.ctypes.data, B, agent._h if agent is not None else None, steps,
-                      seed, env_id0, ctr0 & 0xFFFFFFFF, _ptr(actions, C.c_uint8),
-                      _ptr(si, C.c_int64), _ptr(sf, C.c_double), _ptr(acts, C.c_uint8),
-                      _ptr(rew, C.c_double), _ptr(dn, C.c_uint8))
+    lib().orc_rollout_ex(envs.ctypes.data, B, agent._h if agent is not None else None, steps,
+                         seed, env_id0, ctr0 & 0xFFFFFFFF, _ptr(actions, C.c_uint8),
+                         _ptr(si, C.c_int64), _ptr(sf, C.c_double), _ptr(acts, C.c_uint8),
+                         _ptr(rew, C.c_double), _ptr(dn, C.c_uint8), int(env_flags))
     if record:
         return si, sf, acts, rew, dn
     return si, sf

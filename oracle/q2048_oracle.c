@@ -257,6 +257,68 @@ int orc_env_step(orc_env_t *e, int action, uint32_t draw_pos, uint32_t draw_val,
   return valid;
 }
 
+/* --- second env profile: Deep_QLearning/environment/Game2048_nopenalty_env.py ------------
+ * The DQN path's copy of the env.  Differences from Game2048_env.step, all restated here:
+ *   - Game2048.move works on a COPY, `moved_board` (:58); `board` itself is only replaced by
+ *     the caller (Deep_QLearning/main_dir/mainDQL_CNN_step2.py:237 `env.game.board =
+ *     next_state`), which this restatement folds into the step: on return e->board holds
+ *     moved_board.
+ *   - is_game_over (:68-78) looks at `board`, i.e. the position BEFORE the move.  With an empty
+ *     cell it is False (:70-71).  On a full board it calls move(action) -- not a trial -- for
+ *     action 0..3 (:72-74); the first one that moves something leaves ITS result (with its own
+ *     spawn, two further draws) in moved_board and returns False (:75-77): the board the step
+ *     returns is then that move's, not the chosen action's.  If none moves, moved_board ends as
+ *     a copy of the unchanged board and the game is over.
+ *   - reward = calculate_reward2 (:122-138): -10 for an invalid move while the game is not over,
+ *     otherwise the merge score of the CHOSEN action; no shaping, no normalisation, no stall
+ *     rule.  done = game_over (:117-118).  max_number is taken from moved_board (:109).
+ * over_pos / over_val are the two draws of the spawn inside is_game_over's move. */
+int orc_env_step_dqn(orc_env_t *e, int action, uint32_t draw_pos, uint32_t draw_val,
+                     uint32_t over_pos, uint32_t over_val, double *reward, int *done,
+                     int *max_log2) {
+  const int n = e->n;
+  uint8_t moved[ORC_MAXCELLS];
+  int64_t score = 0;
+  memcpy(moved, e->board, ORC_MAXCELLS);                            /* :58 */
+  int valid = orc_move(moved, n, action, &score);                   /* :107 -> :53-63 */
+  if (valid < 0) return -1;
+  if (valid) orc_add_number(moved, n, draw_pos, draw_val);          /* :64-65 */
+  int game_over = 0;                                                /* :108 -> :68-78 */
+  if (orc_count_empty(e->board, n) == 0) {                          /* :70 */
+    game_over = 1;
+    for (int a = 0; a < 4; ++a) {                                   /* :72 */
+      int64_t s2 = 0;
+      memcpy(moved, e->board, ORC_MAXCELLS);                        /* :58 again: moved_board is rebuilt */
+      if (orc_move(moved, n, a, &s2) > 0) {                         /* :74 */
+        orc_add_number(moved, n, over_pos, over_val);               /* :64-65 */
+        game_over = 0;                                              /* :75-77 */
+        break;
+      }
+    }
+  }
+  const int mx = orc_max_log2(moved, n);                            /* :109 */
+  e->move_score = score;                                            /* :111 */
+  e->score += score;                                                /* :112 */
+  double r;
+  if (!valid && !game_over) r = -10;                                /* :125-126 */
+  else r = (double)score;                                           /* :127-128 */
+  memcpy(e->board, moved, ORC_MAXCELLS);      /* mainDQL_CNN_step2.py:237 env.game.board = next_state */
+  *reward = r;
+  *done = game_over;                                                /* :117-118 */
+  *max_log2 = mx;
+  return valid;
+}
+
+/* SURVEY 7.8 opt-in (not the reference's behaviour): a reset that also restores the shaping
+ * state Game2048_env.__init__ sets (:87, :92-95), which Game2048_env.reset (:187-191) leaves
+ * untouched. */
+void orc_env_reset_shaping(orc_env_t *e) {
+  e->previous_max_log2 = 1;
+  e->consecutive_action = ORC_NO_ACTION;
+  e->consecutive_count = 0;
+  e->last_consecutive_penalty = -1;
+}
+
 int orc_sizeof_env(void) { return (int)sizeof(orc_env_t); }
 
 /* ===================================================================================
@@ -450,6 +512,14 @@ void orc_rollout(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t steps,
                  uint64_t seed, uint64_t env_id0, uint32_t ctr0, const uint8_t *actions,
                  int64_t *stats_i, double *stats_f, uint8_t *out_actions,
                  double *out_reward, uint8_t *out_done) {
+  orc_rollout_ex(envs, B, agent, steps, seed, env_id0, ctr0, actions, stats_i, stats_f,
+                 out_actions, out_reward, out_done, 0);
+}
+
+void orc_rollout_ex(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t steps,
+                    uint64_t seed, uint64_t env_id0, uint32_t ctr0, const uint8_t *actions,
+                    int64_t *stats_i, double *stats_f, uint8_t *out_actions,
+                    double *out_reward, uint8_t *out_done, int env_flags) {
   for (int64_t t = 0; t < steps; ++t) {
     for (int64_t i = 0; i < B; ++i) {
       orc_env_t *e = &envs[i];
@@ -463,7 +533,14 @@ void orc_rollout(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t steps,
       else a = actions[t * B + i];
       double r; int done, mx;
       int64_t size0 = agent ? agent->q->size : 0;
-      int valid = orc_env_step(e, a, x[2], x[3], &r, &done, &mx);          /* :93 */
+      int valid;
+      if (env_flags & ORC_ENV_DQN) {
+        uint32_t y[4];
+        orc_draws(seed, id, ctr0 + (uint32_t)t, ORC_STREAM_OVER, y);
+        valid = orc_env_step_dqn(e, a, x[2], x[3], y[0], y[1], &r, &done, &mx);
+      } else {
+        valid = orc_env_step(e, a, x[2], x[3], &r, &done, &mx);            /* :93 */
+      }
       if (agent) orc_agent_update(agent, s, a, r, e->board, done);         /* :99 */
       e->episode_return += r;                                              /* :101 */
       if (out_actions) out_actions[t * B + i] = (uint8_t)a;
@@ -490,6 +567,7 @@ void orc_rollout(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t steps,
         e->episode += 1;
         orc_draws(seed, id, e->episode, ORC_STREAM_RESET, d);
         orc_env_reset(e, d);                                               /* :81 */
+        if (env_flags & ORC_ENV_RESET_SHAPING) orc_env_reset_shaping(e);
       }
     }
   }

@@ -498,8 +498,118 @@ def gen_g6(env_mod, agent_mod):
               "episodes", len(tr["ep_returns"]), "max tile", int(tr["maxes"].max()))
 
 
+# --------------------------------------------------------------------------------------
+# G8: the DQN path's env (Deep_QLearning/environment/Game2048_nopenalty_env.py): step() with
+# calculate_reward2 and done = game_over.  It imports gymnasium (stubbed above), numpy, math and
+# collections only -- no TensorFlow.  In this env is_game_over's moves are real (their spawn
+# draws are consumed and their result stays in moved_board), so nothing is fed as a dummy.
+# --------------------------------------------------------------------------------------
+def import_reference_dqn_env():
+    import_reference()                                   # registers the gymnasium stub
+    spec = importlib.util.spec_from_file_location(
+        "ref_dqn_env", os.path.join(REF, "Deep_QLearning", "environment", "Game2048_nopenalty_env.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                         # __main__ guard keeps its smoke loop off
+    return mod
+
+
+class InjectedDqn:
+    """np.random.randint / np.random.random <- the feed.  The only other patch is a router around
+    Game2048.is_game_over: while it runs, draws come from `feed.over_q` instead of `feed.env_q`,
+    so that the spawn of the chosen move and the spawn inside is_game_over's move each take the
+    pair the build assigns to them whichever of the two happen (behaviour is untouched)."""
+
+    def __init__(self, dqn_mod, feed: Feed):
+        self.mod, self.feed = dqn_mod, feed
+
+    def __enter__(self):
+        f = self.feed
+        f.over_q = []
+        self.saved = (np.random.randint, np.random.random, self.mod.Game2048.is_game_over)
+        np.random.randint, np.random.random = f.np_randint, f.np_random
+        orig_over = self.saved[2]
+
+        def over(game):
+            f.env_q, f.over_q = f.over_q, f.env_q
+            try:
+                return orig_over(game)
+            finally:
+                f.env_q, f.over_q = f.over_q, f.env_q
+
+        self.mod.Game2048.is_game_over = over
+        return f
+
+    def __exit__(self, *exc):
+        np.random.randint, np.random.random, self.mod.Game2048.is_game_over = self.saved
+
+
+def gen_g8(dqn_mod, count=6000, transcript_steps=4000):
+    rng = np.random.default_rng(8)
+    boards = random_boards(rng, count, full_frac=0.45)   # many full boards: the is_game_over path
+    actions = rng.integers(0, 4, size=count).astype(np.uint8)
+    draws4 = rng.integers(0, 2 ** 32, size=(count, 4), dtype=np.uint64).astype(np.uint32)
+    score0 = rng.integers(0, 5000, size=count).astype(np.int64)
+    out = {k: [] for k in ("boards_out", "reward", "done", "max", "score", "used")}
+    feed = Feed()
+    with InjectedDqn(dqn_mod, feed):
+        for i in range(count):
+            feed.env_q = [0] * 4
+            e = dqn_mod.Game2048_env()
+            e.game.board = raw(boards[i]).astype(int)
+            e.score = int(score0[i])
+            feed.env_q = [int(draws4[i, 0]), int(draws4[i, 1])]      # spawn of the chosen move
+            feed.over_q = [int(draws4[i, 2]), int(draws4[i, 3])]     # spawn inside is_game_over
+            b, r, d, m = e.step(int(actions[i]))
+            out["boards_out"].append(lg(b))
+            out["reward"].append(float(r))
+            out["done"].append(bool(d))
+            out["max"].append(int(m))
+            out["score"].append(int(e.score))
+            out["used"].append((2 - len(feed.env_q)) + 4 * (2 - len(feed.over_q)))
+    # a whole random-play run with the caller's write-back (mainDQL_CNN_step2.py:237
+    # `env.game.board = next_state`) and reset on done (:151), driven by the build's counter RNG:
+    # action = draw_action(x1); spawn draws x2, x3; is_game_over's spawn: stream 2, words 0, 1
+    seed, env_id = 88, 4242
+    tb, tr, td, tm, ta = [], [], [], [], []
+    with InjectedDqn(dqn_mod, feed):
+        feed.env_q = [int(v) for v in O.draws(seed, env_id, 0, O.STREAM_RESET)]
+        e = dqn_mod.Game2048_env()
+        episode = 0
+        board0 = lg(e.game.board)
+        for t in range(transcript_steps):
+            x = O.draws(seed, env_id, t, O.STREAM_STEP)
+            y = O.draws(seed, env_id, t, 2)
+            a = O.draw_action(int(x[1]))
+            feed.env_q, feed.over_q = [int(x[2]), int(x[3])], [int(y[0]), int(y[1])]
+            nb, r, d, m = e.step(a)
+            e.game.board = nb                                                   # :237
+            ta.append(a); tb.append(lg(nb)); tr.append(float(r)); td.append(bool(d)); tm.append(int(m))
+            if d:
+                episode += 1
+                feed.env_q = [int(v) for v in O.draws(seed, env_id, episode, O.STREAM_RESET)]
+                e.reset()                                                       # :151
+        final_board = lg(e.game.board)
+    np.savez_compressed(
+        os.path.join(HERE, "g8_dqn_env.npz"), boards=boards, actions=actions, draws=draws4,
+        score_in=score0, boards_out=np.array(out["boards_out"], dtype=np.uint8),
+        reward=np.array(out["reward"], dtype=np.float64), done=np.array(out["done"], dtype=np.uint8),
+        max=np.array(out["max"], dtype=np.int64), score=np.array(out["score"], dtype=np.int64),
+        draws_used=np.array(out["used"], dtype=np.uint8),
+        t_seed=seed, t_env_id=env_id, t_board0=board0, t_actions=np.array(ta, dtype=np.uint8),
+        t_boards=np.array(tb, dtype=np.uint8), t_reward=np.array(tr, dtype=np.float64),
+        t_done=np.array(td, dtype=np.uint8), t_max=np.array(tm, dtype=np.int64),
+        t_final_board=final_board, t_episodes=episode)
+    print("G8 dqn env:", count, "steps; done", int(np.sum(out["done"])), "draw-pair use {0: none, 2: move, "
+          "8: is_game_over, 10: both}", np.bincount(out["used"], minlength=11)[[0, 2, 8, 10]].tolist(),
+          "| transcript", transcript_steps, "steps,", episode, "episodes")
+
+
 def main():
+    if "--only-g8" in sys.argv:
+        gen_g8(import_reference_dqn_env())
+        return
     env_mod, agent_mod = import_reference()
+    gen_g8(import_reference_dqn_env())
     gen_g1(env_mod)
     gen_g2(env_mod)
     gen_g3(env_mod)

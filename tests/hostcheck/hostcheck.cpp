@@ -24,6 +24,27 @@ static void store_aux(uint8_t* p, const Aux& a) {
   std::memcpy(p, &w, 16);
 }
 
+template <int ENV, class BoardT, class Load, class Store>
+static void rollout_profile(uint8_t* boards, uint8_t* aux, int64_t n, int64_t steps, uint64_t seed,
+                            uint64_t env_id0, uint32_t ctr0, const uint8_t* actions, float* reward,
+                            uint8_t* done, int stride, Load load, Store store) {
+  for (int64_t t = 0; t < steps; ++t)
+    for (int64_t i = 0; i < n; ++i) {
+      BoardT b = load(boards + stride * i);
+      Aux a = load_aux(aux + 16 * i);
+      const uint64_t id = env_id0 + (uint64_t)i;
+      const Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
+      Draws y{0u, 0u, 0u, 0u};
+      if (ENV & kEnvDqn) y = draws(seed, id, ctr0 + (uint32_t)t, kStreamOver);
+      StepOut o = env_step_profile<ENV>(b, a, actions[t * n + i], x.x2, x.x3, y.x0, y.x1);
+      reward[t * n + i] = o.reward; done[t * n + i] = o.done;
+      if (o.done) begin_episode(b, a, seed, id, (ENV & kEnvResetShaping) != 0);
+      store(boards + stride * i, b);
+      store_aux(aux + 16 * i, a);
+    }
+}
+
+
 extern "C" {
 
 void hc_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) {
@@ -202,6 +223,46 @@ void hc5_rollout_env(uint8_t* boards, uint8_t* aux, int64_t n, int64_t steps, ui
       board5_to_bytes(b, boards + 25 * i);
       store_aux(aux + 16 * i, a);
     }
+}
+
+// env profiles: the DQN path's step (draws4 = pos, val, over_pos, over_val per env) and rollouts
+// with a profile (ENV bits of q2048_core.hpp: 1 = DQN step, 2 = resets restore the shaping state)
+void hc_env_step_dqn(uint8_t* boards, uint8_t* aux, const uint8_t* actions, const uint32_t* draws4,
+                     int64_t n, int side, float* reward, uint8_t* done, uint8_t* mx, uint8_t* valid) {
+  for (int64_t i = 0; i < n; ++i) {
+    Aux a = load_aux(aux + 16 * i);
+    const uint32_t* d = draws4 + 4 * i;
+    StepOut o;
+    if (side == 4) {
+      Board b = load_board(boards + 16 * i);
+      o = env_step_dqn(b, a, actions[i], d[0], d[1], d[2], d[3]);
+      store_board(boards + 16 * i, b);
+    } else {
+      Board5 b = board5_from_bytes(boards + 25 * i);
+      o = env_step_dqn(b, a, actions[i], d[0], d[1], d[2], d[3]);
+      board5_to_bytes(b, boards + 25 * i);
+    }
+    store_aux(aux + 16 * i, a);
+    reward[i] = o.reward; done[i] = o.done; mx[i] = o.max_log2; valid[i] = o.valid;
+  }
+}
+
+void hc_rollout_env_profile(uint8_t* boards, uint8_t* aux, int64_t n, int side, int env,
+                            int64_t steps, uint64_t seed, uint64_t env_id0, uint32_t ctr0,
+                            const uint8_t* actions, float* reward, uint8_t* done) {
+  auto l4 = [](const uint8_t* p) { return load_board(p); };
+  auto s4 = [](uint8_t* p, const Board& b) { store_board(p, b); };
+  auto l5 = [](const uint8_t* p) { return board5_from_bytes(p); };
+  auto s5 = [](uint8_t* p, const Board5& b) { board5_to_bytes(b, p); };
+#define HC_CASE(E)                                                                                  \
+  case E:                                                                                           \
+    if (side == 4) rollout_profile<E, Board>(boards, aux, n, steps, seed, env_id0, ctr0, actions,   \
+                                             reward, done, 16, l4, s4);                             \
+    else rollout_profile<E, Board5>(boards, aux, n, steps, seed, env_id0, ctr0, actions, reward,    \
+                                    done, 25, l5, s5);                                              \
+    break;
+  switch (env & 3) { HC_CASE(0) HC_CASE(1) HC_CASE(2) HC_CASE(3) }
+#undef HC_CASE
 }
 
 void hc_kth_set_bit32(const uint32_t* mask, const uint8_t* k, int64_t n, uint8_t* out) {

@@ -430,3 +430,55 @@ def test_5x5_rollout_env_only_matches_oracle(hc, O):
     assert np.array_equal(aux["score"], envs["score"])
     assert np.array_equal(aux["episode"], envs["episode"])
     assert np.array_equal(aux["prev_max"], envs["previous_max_log2"])
+
+
+# ---- env profiles: the DQN path's step (Game2048_nopenalty_env.py) and the shaping-state reset ----
+def test_g8_dqn_env_step_vs_reference(hc):
+    """The device arithmetic of the second env profile against the 6000 reference `step` calls."""
+    g = load_npz("g8_dqn_env.npz")
+    boards = np.ascontiguousarray(g["boards"], dtype=np.uint8).copy()
+    n = len(boards)
+    aux = np.zeros(n, dtype=AUX_DTYPE)
+    aux["score"], aux["prev_max"], aux["cons_action"] = g["score_in"], 1, 0xFF
+    r = np.zeros(n, np.float32); done = np.zeros(n, np.uint8); mx = np.zeros(n, np.uint8)
+    valid = np.zeros(n, np.uint8)
+    hc.hc_env_step_dqn(p(boards), p(aux), p(np.ascontiguousarray(g["actions"])),
+                       p(np.ascontiguousarray(g["draws"], dtype=np.uint32)), C.c_int64(n), 4,
+                       p(r), p(done), p(mx), p(valid))
+    assert np.array_equal(boards, g["boards_out"])
+    assert np.array_equal(r.astype(np.float64), g["reward"])          # scores and -10: exact in f32
+    assert np.array_equal(done, g["done"]) and np.array_equal(aux["score"], g["score"])
+    assert np.array_equal(np.where(mx > 0, 1 << mx.astype(np.int64), 0), g["max"])
+    assert np.array_equal(aux["prev_max"], np.ones(n)) and np.all(aux["cons_count"] == 0)  # untouched
+
+
+def _hc_rollout_profile(hc, O, side, env, B, steps, seed, id0, actions):
+    cells = side * side
+    envs = O.envs_init(B, side, seed, id0)
+    boards = np.ascontiguousarray(envs["board"][:, :cells]).copy()
+    aux = np.zeros(B, dtype=AUX_DTYPE)
+    aux["prev_max"], aux["cons_action"] = 1, 0xFF
+    rew = np.zeros((steps, B), np.float32); dn = np.zeros((steps, B), np.uint8)
+    hc.hc_rollout_env_profile(p(boards), p(aux), C.c_int64(B), side, env, C.c_int64(steps),
+                              C.c_uint64(seed), C.c_uint64(id0), C.c_uint32(0), p(actions), p(rew), p(dn))
+    si, sf, _, orew, odn = O.rollout(envs, None, steps, seed, id0, 0, actions=actions, record=True,
+                                     env_flags=env)
+    return boards, aux, rew, dn, envs, orew, odn
+
+
+@pytest.mark.parametrize("side,env", [(4, 1), (5, 1), (4, 2), (5, 2), (4, 3)])
+def test_env_profile_rollouts_match_oracle(hc, O, side, env):
+    """Rollouts with resets under every env profile, 4x4 and 5x5: boards, rewards, dones, aux."""
+    B, steps, seed, id0 = 96, 700, 11 + env, 5000
+    rng = np.random.default_rng(side * 10 + env)
+    actions = np.where(rng.random((steps, B)) < 0.5, rng.integers(0, 2, size=(steps, B)),
+                       rng.integers(0, 4, size=(steps, B))).astype(np.uint8)
+    actions[:, :8] = 3                      # stall lanes: forced terminations (profiles 0 / 2)
+    boards, aux, rew, dn, envs, orew, odn = _hc_rollout_profile(hc, O, side, env, B, steps, seed, id0, actions)
+    assert np.array_equal(dn, odn) and dn.sum() > 20
+    assert np.array_equal(boards, envs["board"][:, :side * side])
+    assert np.array_equal(rew, orew.astype(np.float32))
+    assert np.array_equal(aux["score"], envs["score"]) and np.array_equal(aux["episode"], envs["episode"])
+    if not env & 1:                         # the DQN step keeps no shaping state
+        assert np.array_equal(aux["prev_max"], envs["previous_max_log2"])
+        assert np.array_equal(aux["cons_count"], np.minimum(envs["consecutive_count"], 60000))

@@ -210,6 +210,112 @@ def test_abi_argument_errors(pkg):
         pkg.BatchedGame2048Env(4, board_size=6, device=DEV)
     with pytest.raises(RuntimeError):
         pkg.BatchedGame2048Env(4, device="cpu")
+    # a batch whose grid would not fit HIP's 32-bit grid.x is a size error, not a truncated launch
+    too_big = (2 ** 31 - 1) * 256 + 1
+    assert L.q2048_env_init(b.data_ptr(), a.data_ptr(), too_big, 4, 0, 0, None) == -2
+    assert L.q2048_legal_moves(b.data_ptr(), too_big, 4, a.data_ptr(), None) == -2
+    assert L.q2048_encode_onehot(b.data_ptr(), (2 ** 31 - 1) * 4 + 1, 0, a.data_ptr(), None) == -2
+    with pytest.raises(ValueError):
+        pkg.BatchedGame2048Env(4, profile="other", device=DEV)
+
+
+# ---------------------------------------------------------------------------------------------
+# env profiles: the DQN path's env (Game2048_nopenalty_env.py) and the shaping-state reset
+# ---------------------------------------------------------------------------------------------
+def test_golden_g8_dqn_env_on_device(pkg):
+    """6000 reference `step` calls of Deep_QLearning/environment/Game2048_nopenalty_env.py
+    (calculate_reward2, done = game_over, the is_game_over quirks) with both draw pairs injected,
+    through q2048_env_step_ex(Q2048_FLAG_ENV_DQN)."""
+    g = load_npz("g8_dqn_env.npz")
+    n = len(g["boards"])
+    N = pkg._native
+    aux = np.zeros(n, dtype=pkg.AUX_DTYPE)
+    aux["score"], aux["prev_max"], aux["cons_action"] = g["score_in"], 1, 0xFF
+    tb, ta = t8(g["boards"]), torch.from_numpy(aux.view(np.uint8).reshape(n, 16).copy()).to(DEV)
+    d4 = torch.from_numpy(np.ascontiguousarray(g["draws"], dtype=np.uint32).view(np.int32)).to(DEV)
+    r = torch.empty(n, dtype=torch.float32, device=DEV)
+    d = torch.empty(n, dtype=torch.uint8, device=DEV)
+    m = torch.empty(n, dtype=torch.uint8, device=DEV)
+    st = torch.zeros(1, dtype=torch.int32, device=DEV)
+    N.check(N.lib().q2048_env_step_ex(tb.data_ptr(), ta.data_ptr(), t8(g["actions"]).data_ptr(), n, 4,
+                                      0, 0, 0, N.FLAG_ENV_DQN, d4.data_ptr(), r.data_ptr(),
+                                      d.data_ptr(), m.data_ptr(), st.data_ptr(), None), "env_step_ex")
+    torch.cuda.synchronize()
+    assert int(st.item()) == 0
+    assert np.array_equal(tb.cpu().numpy(), g["boards_out"])
+    assert np.array_equal(r.cpu().numpy().astype(np.float64), g["reward"])   # scores and -10: exact
+    assert np.array_equal(d.cpu().numpy(), g["done"])
+    mm = m.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.where(mm > 0, 1 << mm, 0), g["max"])
+    a = ta.cpu().numpy().view(pkg.AUX_DTYPE).reshape(-1)
+    assert np.array_equal(a["score"], g["score"])
+    assert np.all(a["prev_max"] == 1) and np.all(a["cons_count"] == 0)       # no shaping state
+
+
+@pytest.mark.parametrize("n,profile,reset_shaping", [(4, "nopenalty", False), (5, "nopenalty", False),
+                                                      (4, "shaped", True), (5, "shaped", True),
+                                                      (4, "nopenalty", True)])
+def test_env_profiles_fused_and_unfused_match_oracle(pkg, O, n, profile, reset_shaping):
+    """Every env profile through BOTH device paths -- the fused rollout and the 4-call API -- on
+    independent lanes (eps = 0.25: argmax over learnt rows) against per-lane oracle agents:
+    boards and aux bit-exact, every Q row within rtol 1e-5.  Lanes stuck on one action make the
+    stall rule end episodes, which is where the shaping-state reset differs from the reference."""
+    B, steps, seed, id0, eps, lr, gamma = 160, 500, 41, 77000, 0.25, 0.1, 0.95
+    flags = (O.ENV_DQN if profile == "nopenalty" else 0) | (O.ENV_RESET_SHAPING if reset_shaping else 0)
+    envs = O.envs_init(B, n, seed, id0)
+    agents = [O.Agent(100, 4, lr, gamma, eps, n=n) for _ in range(B)]
+    episodes = 0
+    for i in range(B):
+        si, sf = O.rollout(envs[i:i + 1], agents[i], steps, seed, id0 + i, 0, env_flags=flags)
+        episodes += int(si[O.ST_EPISODES])
+    assert episodes > 50
+
+    def mk():
+        e = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV,
+                                   profile=profile, reset_shaping_state=reset_shaping)
+        a = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma,
+                                      exploration_rate=eps, capacity_log2=19, seed=seed, env_id0=id0,
+                                      device=DEV, independent=True, board_size=n)
+        return e, a
+
+    e1, a1 = mk()
+    for k in (1, 199, 300):
+        a1.fused_rollout(e1, k)
+    e2, a2 = mk()
+    _unfused_loop(pkg, e2, a2, steps)
+    for what, e, a in (("fused", e1, a1), ("unfused", e2, a2)):
+        assert np.array_equal(e.boards.cpu().numpy(), envs["board"][:, :n * n]), what
+        f = e.aux_fields()
+        assert np.array_equal(f["score"], envs["score"]) and np.array_equal(f["episode"], envs["episode"]), what
+        if profile == "shaped":
+            assert_aux(f, envs, what)
+        for i, oa in enumerate(agents):
+            keys, vals = oa.dump()
+            got = a.q_values(t8(keys), env_id=id0 + i).cpu().numpy()
+            assert np.allclose(got, vals, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(vals).max()))), (what, i)
+        assert a.table_size() == sum(len(oa) for oa in agents), what
+        assert a.check_status() == 0 and e.check_status() == 0
+    assert a1.stats()["episodes"] == episodes
+
+
+def test_play_only_never_touches_the_table(pkg, O):
+    """Q2048_FLAG_PLAY_ONLY at eps = 1 = uniformly random play: the same boards as the learner at
+    eps = 1 (actions come from the draws alone), a table that stays all zeros, no drops."""
+    B, steps, seed, id0 = 5000, 130, 6, 99
+    env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2=16, seed=seed,
+                                      env_id0=id0, device=DEV)          # far too small to learn in
+    agent.fused_rollout(env, 30, play_only=True)
+    agent.fused_rollout(env, steps - 30, play_only=True)
+    envs = O.envs_init(B, 4, seed, id0)
+    si, sf = O.rollout(envs, O.Agent(100, 4, 0.1, 0.9, 1.0), steps, seed, id0, 0)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16])
+    assert_aux(env.aux_fields(), envs, "play only")
+    assert int(torch.count_nonzero(agent.table)) == 0 and agent.table_size() == 0
+    st = agent.stats()
+    assert st["steps"] == B * steps and st["episodes"] == si[O.ST_EPISODES]
+    assert st["inserts"] == 0 and st["drops"] == 0 and agent.check_status() == 0
+    assert np.isclose(st["reward_sum"], sf[O.SF_REWARD], rtol=1e-5)
 
 
 def _env_rollout_device(pkg, B, steps, seed, id0, actions):
@@ -449,14 +555,25 @@ def test_fused_equals_unfused_and_split_launches(pkg, O):
 def test_shared_table_pure_exploration_trajectories_exact(pkg, O):
     """eps = 1: actions come from the draws alone, so every board trajectory is independent of
     the (racy) shared table and must equal the oracle bit for bit at any batch size."""
-    B, steps, seed, id0 = 20000, 150, 4, 55
+    B, steps, seed, id0, lr = 20000, 150, 4, 55, 0.1
     env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
-    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2=23, seed=seed,
+    # gamma = 0: the TD target is the reward alone (Agent/main.py:42), so the value of an entry
+    # depends only on the rewards applied to it, not on when its neighbours were updated
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, learning_rate=lr,
+                                      discount_factor=0.0, capacity_log2=23, seed=seed,
                                       env_id0=id0, device=DEV)
     agent.fused_rollout(env, steps)
     envs = O.envs_init(B, 4, seed, id0)
-    oa = O.Agent(100, 4, 0.1, 0.9, 1.0)
-    si, sf = O.rollout(envs, oa, steps, seed, id0, 0)
+    oa = O.Agent(100, 4, lr, 0.0, 1.0)
+    si, sf = np.zeros(O.ST_NI, np.int64), np.zeros(O.SF_NF)
+    touched = []                                 # (state key, action, reward) of every update
+    for t in range(steps):
+        s = envs["board"][:, :16].copy()
+        i1, f1, acts, rew, dn = O.rollout(envs, oa, 1, seed, id0, t, record=True)
+        si += i1; sf += f1
+        key = (s.astype(np.uint64) << (4 * np.arange(16, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+        touched.append(np.stack([key, acts[0].astype(np.uint64),
+                                 rew[0].astype(np.float32).view(np.uint32).astype(np.uint64)], axis=1))
     assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16])
     assert_aux(env.aux_fields(), envs, "shared eps=1")
     st = agent.stats()
@@ -469,10 +586,43 @@ def test_shared_table_pure_exploration_trajectories_exact(pkg, O):
     keys, vals = oa.dump()
     q, found = agent.q_values(t8(keys), return_found=True)
     assert bool(found.cpu().numpy().all())
-    # sequential (oracle) vs concurrent (device) update order differs only where lanes share a
-    # state; rows touched once must agree to float32 tolerance
+    # sequential (oracle) vs concurrent (device) update order differs only where lanes share an
+    # entry: every (s, a) updated exactly once in the whole run holds lr * reward on both sides
+    # (device vs the formula AND vs the oracle's float64 table), an entry updated k times holds a
+    # value between the extremes of {0, its rewards} (each update moves it a fraction lr towards
+    # one of them), and entries of touched rows that no update wrote are exactly 0
     d = agent.export_dict()
     assert len(d) == agent.table_size()
+    tch = np.concatenate(touched)
+    order = np.lexsort((tch[:, 1], tch[:, 0]))
+    sp = tch[order, :2]                                       # (key, action), grouped
+    rw = tch[order, 2].astype(np.uint32).view(np.float32).astype(np.float64)
+    new = np.ones(len(sp), dtype=bool)
+    new[1:] = (sp[1:] != sp[:-1]).any(axis=1)
+    starts = np.flatnonzero(new)
+    counts = np.diff(np.append(starts, len(sp)))
+    ent_key, ent_act = sp[starts, 0], sp[starts, 1].astype(np.int64)
+
+    def unpack(k):
+        return np.stack([(k >> np.uint64(4 * c)) & np.uint64(15) for c in range(16)], axis=1)
+
+    rows_k, row_of = np.unique(ent_key, return_inverse=True)
+    q_rows = agent.q_values(t8(unpack(rows_k))).cpu().numpy().astype(np.float64)
+    got = q_rows[row_of, ent_act]
+    once = counts == 1
+    assert once.sum() > 0.5 * len(starts)                     # most entries are touched once
+    assert np.allclose(got[once], lr * rw[starts[once]], rtol=1e-5, atol=1e-6)
+    okeys = (keys.astype(np.uint64) << (4 * np.arange(16, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+    osort = np.argsort(okeys)
+    q_orc = vals[osort][np.searchsorted(okeys[osort], ent_key), ent_act]
+    assert np.allclose(got[once], q_orc[once], rtol=1e-5, atol=1e-6)
+    lo = np.minimum.reduceat(np.minimum(rw, 0.0), starts)
+    hi = np.maximum.reduceat(np.maximum(rw, 0.0), starts)
+    assert np.all(got >= lo - 1e-6) and np.all(got <= hi + 1e-6)
+    touched_a = np.zeros((len(rows_k), 4), dtype=bool)
+    touched_a[row_of, ent_act] = True
+    assert np.all(q_rows[~touched_a] == 0.0)
+    print(f"[q] shared eps=1: {int(once.sum())} of {len(starts)} entries touched once, all equal lr * reward")
     assert agent.check_status() == 0
 
 
@@ -669,6 +819,103 @@ def test_full_size_1m_boards_properties(pkg, O, B, launches, S, cap):
     st2 = agent2.stats()
     for k in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "max_tile_hist"):
         assert st[k] == st2[k], k
+
+
+@pytest.mark.parametrize("B", [1 << 20, (1 << 20) + 77])
+def test_5x5_full_size_1m_boards(pkg, O, B):
+    """BASELINE configs[4] at its stated size: 1,048,576 5x5 boards through the fused kernel on a
+    shared table (and the same + 77 lanes, so that the last block of the 25-byte board stream is
+    ragged).  eps = 1: sampled lanes bit-exact against the oracle -- the first and last lanes of
+    the stream, block edges and 1500 random ones, which exercises the 64-bit `base * 25`
+    addressing of the unpadded stream end to end -- and the whole batch by invariants."""
+    seed, id0, launches, S, cap = 909, 3, 3, 16, 27
+    env = pkg.BatchedGame2048Env(B, board_size=5, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(1000, exploration_rate=1.0, discount_factor=0.99,
+                                      capacity_log2=cap, seed=seed, env_id0=id0, device=DEV,
+                                      board_size=5)
+    for _ in range(launches):
+        agent.fused_rollout(env, S)
+    steps = launches * S
+    boards = env.boards.cpu().numpy()
+    assert boards.shape == (B, 25)
+    aux = env.aux_fields()
+    rng = np.random.default_rng(5)
+    last_block = (B - 1) // 256 * 256
+    sample = np.unique(np.concatenate([[0, 1, 63, 64, 255, 256, 257, last_block - 1, last_block,
+                                        B - 2, B - 1], rng.integers(0, B, size=1500)]))
+    for i in sample.tolist():
+        envs = O.envs_init(1, 5, seed, id0 + i)
+        O.rollout(envs, O.Agent(10, 4, 0.1, 0.99, 1.0, n=5), steps, seed, id0 + i, 0)
+        assert boards[i].tolist() == envs["board"][0, :25].tolist(), i
+        assert aux["score"][i] == envs["score"][0] and aux["episode"][i] == envs["episode"][0], i
+        assert aux["cons_count"][i] == envs["consecutive_count"][0], i
+        assert aux["prev_max"][i] == envs["previous_max_log2"][0], i
+    st = agent.stats()
+    assert st["steps"] == B * steps and st["explored"] == B * steps
+    assert st["episodes"] == int(aux["episode"].astype(np.int64).sum())
+    assert st["inserts"] == agent.table_size() and st["drops"] == 0
+    assert agent.check_status() == 0 and env.check_status() == 0
+    assert pkg._native.claim_timeouts() == 0
+    assert boards.max() <= 31 and (boards > 0).sum(axis=1).min() >= 2
+    # a second run in one launch instead of three: same boards, same statistics
+    del agent
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    env2 = pkg.BatchedGame2048Env(B, board_size=5, seed=seed, env_id0=id0, device=DEV)
+    agent2 = pkg.BatchedQLearningAgent(1000, exploration_rate=1.0, discount_factor=0.99,
+                                       capacity_log2=cap, seed=seed, env_id0=id0, device=DEV,
+                                       board_size=5)
+    agent2.fused_rollout(env2, steps)
+    assert torch.equal(env.boards, env2.boards) and torch.equal(env.aux, env2.aux)
+    st2 = agent2.stats()
+    for k in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "max_tile_hist"):
+        assert st[k] == st2[k], k
+
+
+@pytest.mark.parametrize("n,cap", [(4, 27), (5, 27)])
+def test_full_size_1m_lanes_q_dependent_actions(pkg, O, n, cap):
+    """1,048,576 lanes with eps = 0.2, so that 80 % of the actions are argmax over Q rows the
+    lane itself learnt (Agent/main.py:38): Q2048_FLAG_INDEPENDENT gives every env private rows,
+    which makes each lane a pure function of its own global id at any batch size.  >= 1000 sampled
+    lanes are compared with one oracle agent each: boards and aux bit-exact, EVERY Q row of the
+    lane within rtol 1e-5 (the north-star tolerance)."""
+    B, seed, id0, eps, lr, gamma, launches, S = 1 << 20, 31, 11, 0.2, 0.1, 0.99, 3, 16
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(1000, learning_rate=lr, discount_factor=gamma,
+                                      exploration_rate=eps, capacity_log2=cap, seed=seed,
+                                      env_id0=id0, device=DEV, independent=True, board_size=n)
+    for _ in range(launches):
+        agent.fused_rollout(env, S)
+    steps = launches * S
+    boards = env.boards.cpu().numpy()
+    aux = env.aux_fields()
+    rng = np.random.default_rng(n)
+    sample = np.unique(np.concatenate([[0, 1, 63, 64, 255, 256, B - 257, B - 2, B - 1],
+                                       rng.integers(0, B, size=1100)]))
+    assert len(sample) >= 1000
+    worst, rows, greedy = 0.0, 0, 0
+    for i in sample.tolist():
+        envs = O.envs_init(1, n, seed, id0 + i)
+        oa = O.Agent(1000, 4, lr, gamma, eps, n=n)
+        si, _ = O.rollout(envs, oa, steps, seed, id0 + i, 0)
+        greedy += steps - int(si[O.ST_EXPLORE])
+        assert boards[i].tolist() == envs["board"][0, :n * n].tolist(), i
+        assert aux["score"][i] == envs["score"][0] and aux["episode"][i] == envs["episode"][0], i
+        assert aux["cons_count"][i] == envs["consecutive_count"][0], i
+        assert aux["cons_action"][i] == envs["consecutive_action"][0] & 0xFF, i
+        keys, vals = oa.dump()
+        got, found = agent.q_values(t8(keys), env_id=id0 + i, return_found=True)
+        assert bool(found.all()), i                      # every row of the reference dict exists
+        got = got.cpu().numpy()
+        assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), i
+        worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
+        rows += len(keys)
+    assert greedy > 0.7 * len(sample) * steps            # the argmax path was the one exercised
+    print(f"[q] {n}x{n} 1M lanes eps={eps}: {len(sample)} lanes, {rows} rows, worst relative Q error {worst:.2e}")
+    st = agent.stats()
+    assert st["steps"] == B * steps and st["drops"] == 0 and st["cas_retries"] == 0
+    assert st["inserts"] == agent.table_size()
+    assert agent.check_status() == 0 and pkg._native.claim_timeouts() == 0
 
 
 def test_table_full_drops_are_counted_not_raised(pkg, O):

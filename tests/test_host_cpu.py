@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), f"{name} declared in include/q2048.h but not exported"
     assert set(pkg._native._SIGNATURES) == declared
     L = pkg._native.lib()
-    assert L.q2048_abi_version() == 1
+    assert L.q2048_abi_version() == pkg._native.ABI_VERSION == 2
     assert L.q2048_sizeof_aux() == 16 and L.q2048_sizeof_slot() == 32
     assert L.q2048_strerror(-4).decode().startswith("unsupported")
     # host-side argument validation needs no device
@@ -216,3 +216,96 @@ def test_world_size_2_gloo_sharding_and_stats_allreduce(pkg, O, tmp_path):
         assert p["slowest"] == 2.0
     assert parts[0]["local_si"][O.ST_STEPS] * 2 == si[O.ST_STEPS]
     assert int(parts[1]["id0"]) == 500 + 48
+
+
+# ---- rank launcher (bench.py --gpus N without torchrun) -----------------------------------------
+_RANK_CHILD = r'''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+mode = sys.argv[1]
+if mode == "fail" and rank == world - 1:
+    sys.exit(7)
+if mode == "fail":
+    time.sleep(60)                      # must be terminated by the launcher, not waited for
+if mode == "gloo":                      # the ranks really can rendezvous on MASTER_ADDR:PORT
+    import torch, torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    total = float(t.item())
+    dist.destroy_process_group()
+else:
+    total = None
+print("noise from rank", rank, file=sys.stderr)
+print(json.dumps({"rank": rank, "world": world, "port": os.environ["MASTER_PORT"], "sum": total}), flush=True)
+'''
+
+
+def _load_launcher():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(
+        "q2048_launch_t", os.path.join(REPO, "2048_q-learning_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_rank_launcher_env_relay_and_failure(tmp_path):
+    """N children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, exactly rank 0's stdout is relayed,
+    a failing child makes the parent's result non-zero and the survivors are terminated."""
+    import io
+    import time
+
+    L = _load_launcher()
+    assert "torch" not in L.__dict__                       # importable before anything heavy
+    assert not L.inside_a_launch({}) and L.inside_a_launch({"RANK": "0", "WORLD_SIZE": "2"})
+    child = tmp_path / "child.py"
+    child.write_text(_RANK_CHILD)
+    buf = io.StringIO()
+    rc = L.launch_ranks([sys.executable, str(child), "ok"], 3, stdout=buf, timeout=60)
+    assert rc == 0
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1                                 # ONE line: rank 0's
+    rec = json.loads(lines[0])
+    assert rec["rank"] == 0 and rec["world"] == 3 and int(rec["port"]) > 0
+    buf = io.StringIO()
+    rc = L.launch_ranks([sys.executable, str(child), "gloo"], 2, stdout=buf, timeout=120)
+    assert rc == 0 and json.loads(buf.getvalue().strip().splitlines()[-1])["sum"] == 3.0   # gloo chats on stdout
+    t0 = time.monotonic()
+    rc = L.launch_ranks([sys.executable, str(child), "fail"], 2, stdout=io.StringIO(), timeout=50)
+    assert rc == 7 and time.monotonic() - t0 < 30          # did not wait for the sleeping rank
+    rc = L.launch_ranks([sys.executable, "-c", "import time; time.sleep(30)"], 2,
+                        stdout=io.StringIO(), timeout=1.0)
+    assert rc == 124
+
+
+def test_bench_self_launches_its_ranks_and_propagates_failure():
+    """`python bench.py --gpus 2` with no process group in the environment starts its own ranks;
+    on a box without a GPU every rank fails loudly and so does the parent (no hang, no line)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the -m gpu rehearsal")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4",
+                        "--warmup", "1", "--cpu-seconds", "0"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""
+    assert "no HIP device" in p.stderr or "MI355X" in p.stderr
+
+
+def test_stats_allreduce_object_single_process(pkg):
+    import torch
+
+    r = pkg.StatsAllReduce(None)
+    si = torch.arange(pkg._native.NSTAT_I, dtype=torch.int64)
+    sf = torch.ones(pkg._native.NSTAT_F, dtype=torch.float64)
+    r.start(si, sf)
+    si[0] = 99                                             # the snapshot is what gets reduced
+    a, b = r.wait()
+    assert a[0] == 0 and a[5] == 5 and b.tolist() == [1.0] * pkg._native.NSTAT_F
+    with pytest.raises(RuntimeError):
+        r.wait()

@@ -266,3 +266,56 @@ def test_g6_transcripts(O, name):
     got = np.stack([agent.q(k) for k in tr["q_keys"]])
     assert np.array_equal(got, tr["q_vals"])             # float64 bit-exact Q-table
     assert dones.sum() == len(tr["ep_returns"])
+
+
+# ---- G8: the DQN path's env profile (Game2048_nopenalty_env.py:106-138) -------------------------
+def test_g8_dqn_env_steps(O):
+    """6000 reference `step` calls (calculate_reward2, done = game_over on the pre-move board, the
+    board is_game_over's first legal move leaves behind on a full board): boards, reward, done,
+    max tile and score, bit for bit."""
+    g = load_npz("g8_dqn_env.npz")
+    for i in range(len(g["boards"])):
+        e = O.Env(4)
+        e.set_board(g["boards"][i])
+        e.rec["score"][0] = g["score_in"][i]
+        d4 = g["draws"][i]
+        b, r, d, m, valid = e.step_dqn(int(g["actions"][i]), int(d4[0]), int(d4[1]), int(d4[2]), int(d4[3]))
+        assert b.tolist() == g["boards_out"][i].tolist(), i
+        assert r == g["reward"][i] and d == bool(g["done"][i]), i
+        assert (1 << m if m else 0) == g["max"][i] and e.rec["score"][0] == g["score"][i], i
+    assert g["done"].sum() > 100 and (g["draws_used"] == 10).sum() > 1000   # both draw pairs in play
+
+
+def test_g8_dqn_env_transcript(O):
+    """4000 steps of random play through the reference env with the caller's board write-back
+    and resets, against orc_rollout_ex(ORC_ENV_DQN) driven by the same counter draws."""
+    g = load_npz("g8_dqn_env.npz")
+    seed, id0, steps = int(g["t_seed"]), int(g["t_env_id"]), len(g["t_actions"])
+    envs = O.envs_init(1, 4, seed, id0)
+    assert envs["board"][0, :16].tolist() == g["t_board0"].tolist()
+    for t in range(steps):
+        si, sf, a, r, d = O.rollout(envs, None, 1, seed, id0, t, actions=g["t_actions"][t:t + 1],
+                                    record=True, env_flags=O.ENV_DQN)
+        assert r[0, 0] == g["t_reward"][t] and d[0, 0] == g["t_done"][t], t
+        if not d[0, 0]:                       # on done the oracle has already reset in place
+            assert envs["board"][0, :16].tolist() == g["t_boards"][t].tolist(), t
+    assert envs["board"][0, :16].tolist() == g["t_final_board"].tolist()
+    assert int(envs["episode"][0]) == int(g["t_episodes"]) > 10
+
+
+def test_reset_shaping_option(O):
+    """ORC_ENV_RESET_SHAPING: after a forced termination by the stall rule the next episode starts
+    with the constructor's shaping state instead of ending on its first repeated action."""
+    for flags, expect_done_first in ((0, True), (O.ENV_RESET_SHAPING, False)):
+        envs = O.envs_init(1, 4, 3, 0)
+        envs["board"][0, :16] = [1, 2, 3, 4] + [0] * 12            # action 0 never moves this row
+        acts = np.zeros((102, 1), dtype=np.uint8)
+        si, sf, a, r, d = O.rollout(envs, None, 102, 3, 0, 0, actions=acts, record=True,
+                                    env_flags=flags)
+        assert d[100, 0] == 1 and d[:100].sum() == 0               # done at the 101st repeat
+        # step 102 (index 101) is the first step of the next episode, again action 0
+        if expect_done_first:
+            assert d[101, 0] == 1 and envs["consecutive_count"][0] == 102
+        else:
+            assert d[101, 0] == 0 and envs["consecutive_count"][0] == 1
+            assert envs["previous_max_log2"][0] >= 1

@@ -41,10 +41,12 @@ __device__ __forceinline__ uint32_t grind(uint32_t a, uint32_t b, int work) {
   return a ^ b;
 }
 
-enum { kLoad = 1, kCas = 2, kStore = 4, kCasAlways = 8, kStore16 = 16, kStore32 = 32, kCas2 = 64, kKey16 = 128 };
+enum { kLoad = 1, kCas = 2, kStore = 4, kCasAlways = 8, kStore16 = 16, kStore32 = 32, kCas2 = 64, kKey16 = 128,
+       kStore64 = 256, kStore128 = 512, kBmLoad = 1024, kBmOr = 2048, kBmOrAlways = 4096, kLoadIfSet = 8192 };
 
 __global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, int64_t lanes, int steps,
-                                                  int what, int work, uint32_t ctr0, uint32_t* sink) {
+                                                  int what, int work, uint32_t ctr0, uint32_t* sink,
+                                                  uint32_t* bitmap) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= lanes) return;
   uint32_t acc = (uint32_t)i;
@@ -54,7 +56,20 @@ __global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, in
     const uint64_t key = mix(((uint64_t)i << 32) ^ (uint64_t)(ctr0 + (uint32_t)t) ^ ((uint64_t)acc << 13)) | 1ull;
     const uint64_t at = (key >> 7) & mask;
     uint64_t seen = 0ull;
-    if (what & kLoad) {
+    // occupancy bitmap (1 bit per slot, cache-resident up to 2^31 slots): a 4-B sc1 load, then an
+    // atomic OR that claims the slot when the bit was clear
+    bool bit_set = false;
+    if (what & kBmLoad) {
+      uint32_t w;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(&bitmap[at >> 5]) : "memory");
+      bit_set = (w >> (at & 31ull)) & 1u;
+    }
+    if ((what & kBmOrAlways) || ((what & kBmOr) && !bit_set)) {
+      const uint32_t old = atomicOr(&bitmap[at >> 5], 1u << (at & 31ull));
+      acc ^= old;
+      bit_set = bit_set || ((old >> (at & 31ull)) & 1u);
+    }
+    if ((what & kLoad) || ((what & kLoadIfSet) && bit_set)) {
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       u32x4 v;
       asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(&table[at]) : "memory");
@@ -77,6 +92,12 @@ __global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, in
       row[0] = make_uint4((uint32_t)key | 1u, (uint32_t)(key >> 32), acc, acc);
       if (what & kStore32) row[1] = make_uint4(acc, acc, 0u, 0u);
     }
+    if (what & (kStore64 | kStore128)) {       // a whole 64-B / 128-B line written by one lane
+      const uint64_t lines = (what & kStore128) ? 3ull : 1ull;
+      uint4* row = reinterpret_cast<uint4*>(&table[prev & ~lines]);
+      const int n16 = (what & kStore128) ? 8 : 4;
+      for (int k = 0; k < n16; ++k) row[k] = make_uint4((uint32_t)key | 1u, (uint32_t)(key >> 32), acc, (uint32_t)k);
+    }
     prev = at;
   }
   if (acc == 0x12345u) *sink = acc;
@@ -95,7 +116,9 @@ int main(int argc, char** argv) {
   const int64_t lanes = (int64_t)1 << lanes_log2;
   Slot* table;
   uint32_t* sink;
+  uint32_t* bitmap;
   CK(hipMalloc(&table, (1ull << alloc_log2) * sizeof(Slot)));
+  CK(hipMalloc(&bitmap, cap / 8));
   CK(hipMalloc(&sink, 4));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -108,22 +131,30 @@ int main(int argc, char** argv) {
       {"store16", kStore16}, {"store32", kStore32}, {"load+store32", kLoad | kStore32},
       {"load+cas+store32", kLoad | kCas | kStore32},
       {"load+cas+cas2+store", kLoad | kCas | kCas2 | kStore},
-      {"load+cas+key16+store", kLoad | kCas | kKey16 | kStore}};
+      {"load+cas+key16+store", kLoad | kCas | kKey16 | kStore},
+      {"store64", kStore64}, {"store128", kStore128}, {"load+store64", kLoad | kStore64},
+      {"bmload", kBmLoad}, {"bmor(always)", kBmOrAlways}, {"bmload+bmor", kBmLoad | kBmOr},
+      {"bmload+bmor+store32", kBmLoad | kBmOr | kStore32},
+      {"bmload+bmor+store64", kBmLoad | kBmOr | kStore64},
+      {"bmload+bmor+store", kBmLoad | kBmOr | kStore},
+      {"bmor(always)+store32", kBmOrAlways | kStore32},
+      {"bmload+bmor+load(if set)+store32", kBmLoad | kBmOr | kLoadIfSet | kStore32}};
   std::printf("{\"alloc_log2\": %d, \"cap_log2\": %d, \"lanes\": %lld, \"steps\": %d, \"unit\": \"us per step per 2^20 lanes\", \"rows\": [\n",
               alloc_log2, cap_log2, (long long)lanes, steps);
   bool first = true;
   for (auto& c : combos) {
-    for (int work : {0, 5}) {
+    for (int work : {0}) {
       CK(hipMemsetAsync(table, 0, cap * sizeof(Slot), 0));       // every run starts on an empty table
+      CK(hipMemsetAsync(bitmap, 0, cap / 8, 0));
       uint32_t ctr = 0;
       hipLaunchKernelGGL(k_requests, dim3(grid), dim3(256), 0, 0, table, cap - 1, lanes, steps, c.what,
-                         work, ctr, sink);                        // warm-up (fills steps*lanes keys)
+                         work, ctr, sink, bitmap);                // warm-up (fills steps*lanes keys)
       ctr += (uint32_t)steps;
       CK(hipEventRecord(e0, 0));
       const int reps = 3;
       for (int r = 0; r < reps; ++r) {
         hipLaunchKernelGGL(k_requests, dim3(grid), dim3(256), 0, 0, table, cap - 1, lanes, steps, c.what,
-                           work, ctr, sink);
+                           work, ctr, sink, bitmap);
         ctr += (uint32_t)steps;
       }
       CK(hipEventRecord(e1, 0));
@@ -138,6 +169,7 @@ int main(int argc, char** argv) {
   }
   std::printf("\n]}\n");
   CK(hipFree(table));
+  CK(hipFree(bitmap));
   CK(hipFree(sink));
   return 0;
 }
