@@ -332,6 +332,18 @@ __device__ __forceinline__ float td_update(q2048_slot* slot, int a, float guess,
   atomicAdd(&slot->q[a], nq - bits_f32(expect));  // extreme contention: keep the sample
   return nq;
 }
+// Deferred TD writes: while a lane stays in one state (invalid moves: the board did not change)
+// its updates of that row live in registers (`q`) and `pend` has one bit per action written;
+// they reach the table when the lane leaves the state, finishes the episode or the launch ends.
+// One 4-byte store per entry, as td_update's STORE mode: only the moment changes.
+__device__ __forceinline__ void flush_pending(q2048_slot* slot, const Row& q, uint32_t& pend) {
+  unsigned int* w = reinterpret_cast<unsigned int*>(slot->q);
+  if (pend & 1u) w[0] = f32_bits(q.q0);
+  if (pend & 2u) w[1] = f32_bits(q.q1);
+  if (pend & 4u) w[2] = f32_bits(q.q2);
+  if (pend & 8u) w[3] = f32_bits(q.q3);
+  pend = 0u;
+}
 __device__ __forceinline__ uint32_t td_mode_of(uint32_t flags) {
   const uint32_t x = (flags >> 8) & 15u;  // experiment bits (not ABI)
   return x ? x : ((flags & Q2048_FLAG_TD_CAS) ? kTdCas : kTdStorePlain);
@@ -614,8 +626,9 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
     Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
     uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = wave_count(made0), n_drop = 0;
-    uint32_t retries = 0;
+    uint32_t retries = 0, pend = 0;
     double reward_sum = 0.0;
+    const bool may_defer = td_mode == kTdStorePlain && !((flags >> 14) & 1u);  // bit 14: experiment, off
 
     for (int t = 0; t < steps; ++t) {
       const Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
@@ -641,9 +654,17 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
       const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
       float nq = 0.f;
       const bool updated = slot_s >= 0;
-      if (updated)
-        nq = td_update(&table[slot_s], act, row_get(q, act), o.reward, max_next, o.done != 0, lr,
-                       gamma, retries, play_only ? (uint32_t)kTdNone : td_mode);       // :43, :99
+      if (updated) {                                                                   // :43, :99
+        if (same && !o.done && may_defer) {   // the lane stays on this row: keep the write back
+          nq = td_value(row_get(q, act), o.reward, max_next, false, lr, gamma);
+          pend |= 1u << act;
+        } else {
+          nq = td_update(&table[slot_s], act, row_get(q, act), o.reward, max_next, o.done != 0, lr,
+                         gamma, retries, td_mode);
+          pend &= ~(1u << act);
+          if (pend) flush_pending(&table[slot_s], q, pend);
+        }
+      }
       if (o.done) {                                                                    // :103
         // the terminal state's row exists in the reference too (looked up at :41)
         if (!same && slot_n < 0 && slot_n != kNoSlot && !x_noclaim)
@@ -687,6 +708,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
       n_done += wave_count(o.done != 0);
       reward_sum += (double)o.reward;
     }
+    if (pend && slot_s >= 0) flush_pending(&table[slot_s], q, pend);
     bool ins_last = false;  // the claim issued by the last step (its row belongs to the dict too)
     claim_resolve(table, mask, key_s, claim, slot_s, ins_last);
     n_insert += wave_count(ins_last);
@@ -940,43 +962,84 @@ __global__ __launch_bounds__(kBlock) void k_rt_fused_rollout(
 // ---------------------------------------------------------------------------------------------
 // table utilities
 // ---------------------------------------------------------------------------------------------
-// Streams the whole table once: every lane reads the first 16 bytes of a slot ({key, q0, q1}; a
-// wave covers 2 KiB of consecutive slots, four slots per lane in flight), occupied slots are
-// compacted per wave with a ballot and a prefix popcount, and ONE atomic add per wave that holds
-// any row reserves its output range (none at all for the empty stretches that make up most of a
-// sparse table).  Non-temporal loads: a scan must not evict the rows the rollout is working on.
-constexpr int kExportUnroll = 4;
+// Streams the whole table once, in tiles of 16 Ki slots per block: a lane reads the first 16 bytes
+// ({key, q0, q1}) of 64 slots, four in flight at a time, consecutive lanes on consecutive slots,
+// and keeps one occupancy bit per slot.  Counting: the per-lane totals are reduced per block and
+// the block issues ONE global atomic at the very end (same-address atomics run at ~10^8/s: one
+// per occupied wave made the first version of this scan 10x slower than the memory system).
+// Exporting: per tile the block reserves its output range with one atomic, an LDS scan gives
+// every lane its offset, and only the occupied slots are read again for their second half.
+// Non-temporal loads: a scan must not evict the rows a rollout is working on.
+constexpr int kTilePerLane = 64;                        // slots per lane per tile (one mask word)
+constexpr u64 kTileSlots = (u64)kBlock * kTilePerLane;  // 16 Ki slots = 512 KiB of table
 __global__ __launch_bounds__(kBlock) void k_table_export(const q2048_slot* table, u64 cap,
                                                          u64* keys_out, float* q_out, int64_t max_rows,
                                                          int key_words, u64* count) {
-  const u64 stride = (u64)gridDim.x * kBlock;
+  __shared__ uint32_t wave_sum[kBlock / 64];
+  __shared__ u64 tile_base;
   const u32x4* t16 = reinterpret_cast<const u32x4*>(table);
-  const u64 lane_lt = (1ull << (threadIdx.x & 63)) - 1ull;
-  for (u64 i0 = (u64)blockIdx.x * kBlock + threadIdx.x; i0 < cap; i0 += kExportUnroll * stride) {
-    u32x4 v[kExportUnroll];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  u64 total = 0ull;                                     // count-only: this lane's occupied slots
+  for (u64 tile = (u64)blockIdx.x * kTileSlots; tile < cap; tile += (u64)gridDim.x * kTileSlots) {
+    u64 occ = 0ull;
+#pragma unroll 1
+    for (int j = 0; j < kTilePerLane; j += 4) {
+      u32x4 v[4];
 #pragma unroll
-    for (int k = 0; k < kExportUnroll; ++k) {
-      const u64 i = i0 + (u64)k * stride;
-      v[k] = u32x4{0u, 0u, 0u, 0u};
-      if (i < cap) v[k] = __builtin_nontemporal_load(&t16[2ull * i]);
-    }
-#pragma unroll
-    for (int k = 0; k < kExportUnroll; ++k) {
-      const u64 i = i0 + (u64)k * stride;
-      const bool occ = (v[k].x | v[k].y) != 0u;
-      const u64 bal = __ballot(occ);
-      if (bal == 0ull) continue;                       // wave-uniform
-      u64 base = 0ull;
-      if ((u64)(threadIdx.x & 63) == (u64)__ffsll((long long)bal) - 1ull)
-        base = atomicAdd(count, (u64)__popcll(bal));
-      base = __shfl(base, __ffsll((long long)bal) - 1);
-      const u64 at = base + (u64)__popcll(bal & lane_lt);
-      if (occ && keys_out != nullptr && (int64_t)at < max_rows) {
-        const u32x4 w = __builtin_nontemporal_load(&t16[2ull * i + 1ull]);   // {q2, q3, second key word}
-        keys_out[at * (u64)key_words] = (u64)v[k].x | ((u64)v[k].y << 32);
-        if (key_words == 2) keys_out[at * 2ull + 1ull] = (u64)w.z | ((u64)w.w << 32);
-        reinterpret_cast<u32x4*>(q_out)[at] = u32x4{v[k].z, v[k].w, w.x, w.y};
+      for (int k = 0; k < 4; ++k) {
+        const u64 i = tile + (u64)(j + k) * kBlock + threadIdx.x;
+        v[k] = u32x4{0u, 0u, 0u, 0u};
+        if (i < cap) v[k] = __builtin_nontemporal_load(&t16[2ull * i]);
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) occ |= (u64)((v[k].x | v[k].y) != 0u) << (j + k);
+    }
+    const uint32_t mine = (uint32_t)__popcll(occ);
+    if (keys_out == nullptr) { total += mine; continue; }
+    // block-wide exclusive scan of `mine`: wave prefix by shuffles, wave totals through LDS
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incl, d);
+      if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63u) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, block_total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+      before += (uint32_t)w < wave ? wave_sum[w] : 0u;
+      block_total += wave_sum[w];
+    }
+    if (threadIdx.x == 0) tile_base = block_total ? atomicAdd(count, (u64)block_total) : 0ull;
+    __syncthreads();
+    u64 at = tile_base + before + (incl - mine);
+    while (occ != 0ull) {
+      const int j = __ffsll((long long)occ) - 1;
+      occ &= occ - 1ull;
+      if ((int64_t)at < max_rows) {
+        const u64 i = tile + (u64)j * kBlock + threadIdx.x;
+        const u32x4 a = __builtin_nontemporal_load(&t16[2ull * i]);          // {key, q0, q1}
+        const u32x4 w = __builtin_nontemporal_load(&t16[2ull * i + 1ull]);   // {q2, q3, second key word}
+        keys_out[at * (u64)key_words] = (u64)a.x | ((u64)a.y << 32);
+        if (key_words == 2) keys_out[at * 2ull + 1ull] = (u64)w.z | ((u64)w.w << 32);
+        reinterpret_cast<u32x4*>(q_out)[at] = u32x4{a.z, a.w, w.x, w.y};
+      }
+      ++at;
+    }
+    __syncthreads();                                    // wave_sum / tile_base are reused
+  }
+  if (keys_out == nullptr) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+    __shared__ u64 wave_total[kBlock / 64];
+    if (lane == 0u) wave_total[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      u64 sum = 0ull;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) sum += wave_total[w];
+      if (sum) atomicAdd(count, sum);
     }
   }
 }
@@ -1396,8 +1459,8 @@ int q2048_table_export(const q2048_slot* table, int cap_log2, uint64_t* keys_out
   if (key_words != 1 && key_words != 2) return Q2048_ERR_SIZE;
   if (q_out != nullptr && !aligned16(q_out)) return Q2048_ERR_ALIGN;
   const u64 cap = 1ull << cap_log2;
-  const u64 blocks = (cap + (u64)kBlock * kExportUnroll - 1) / ((u64)kBlock * kExportUnroll);
-  // 8 blocks of 4 waves on each of the 256 CUs: the whole device streams, no tail
+  const u64 blocks = (cap + kTileSlots - 1) / kTileSlots;
+  // 8 blocks of 4 waves on each of the 256 CUs: the whole device streams
   hipLaunchKernelGGL(k_table_export, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kBlock), 0,
                      (hipStream_t)stream, table, cap, reinterpret_cast<u64*>(keys_out), q_out,
                      max_rows, key_words, reinterpret_cast<u64*>(count));

@@ -86,6 +86,8 @@ def parse_args(argv=None):
     p.add_argument("--strict-td", action="store_true",
                    help="TD write by compare-and-swap loop (Q2048_FLAG_TD_CAS) instead of one store")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 = skip")
+    p.add_argument("--experiment-bits", type=lambda v: int(v, 0), default=0,
+                   help="unstable tuning bits OR-ed into the fused kernel's flags (ablations; not ABI)")
     p.add_argument("--no-companions", action="store_true",
                    help="skip the 2^28-slot and eps = 0.01 companion runs (N = 1 only anyway)")
     return p.parse_args(argv)
@@ -185,6 +187,7 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
                                           strict_td=args.strict_td, board_size=args.board_size,
                                           placement=placement)
         synth = agent
+        agent.experiment_bits = args.experiment_bits
 
     def run(steps_):
         launches, left = 0, steps_
@@ -336,7 +339,7 @@ def run_rank(args):
                    "table_bytes_per_gpu": (1 << cap_log2) * 32, "epsilon": args.eps,
                    "alpha": args.alpha, "gamma": args.gamma, "seed": args.seed,
                    "td_write": "compare-and-swap" if args.strict_td else "store (last writer wins)",
-                   "table_placement": m["placement"],
+                   "table_placement": m["placement"], "experiment_bits": args.experiment_bits,
                    "prep_steps": args.prep_steps, "repeats": args.repeats,
                    "timing": "median of `repeats` K-step regions after `prep_steps` of random play "
                              "and `warmup` learning steps",

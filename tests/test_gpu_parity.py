@@ -61,7 +61,7 @@ def t8(a):
 # ---------------------------------------------------------------------------------------------
 def test_native_library_is_loaded(pkg):
     lib = pkg._native.lib()
-    assert lib.q2048_abi_version() == 1
+    assert lib.q2048_abi_version() == pkg._native.ABI_VERSION
     assert os.path.samefile(pkg._native.LIB_PATH, os.path.join(os.path.dirname(pkg.__file__),
                                                                 "csrc", "libq2048_hip.so"))
 

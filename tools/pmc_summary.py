@@ -1,47 +1,60 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 counter_collection CSVs: per kernel, per counter: mean over dispatches."""
-import csv, glob, os, sys, collections
+"""Summarise rocprofv3 counter_collection CSVs: per kernel and counter, the mean over the timed
+dispatches (the LAST `timed` dispatches of the kernel: the bench's timed regions come last), per
+dispatch and per env-step.  Usage: pmc_summary.py <pmc dir> <bench json of one pass>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
 root = sys.argv[1]
+bench = json.load(open(sys.argv[2])) if len(sys.argv) > 2 and os.path.getsize(sys.argv[2]) else None
+timed = steps_per_dispatch = None
+if bench:
+    cfg = bench["config"]
+    launches = bench["roofline"]["launches"]
+    timed = launches * cfg["repeats"]
+    steps_per_dispatch = cfg["boards_per_gpu"] * bench["steps"] / launches
+summary = {}
 for d in sorted(glob.glob(os.path.join(root, "pass*"))):
-    if not os.path.isdir(d): continue
-    acc = collections.defaultdict(list)
+    if not os.path.isdir(d):
+        continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r.get("Kernel_Name", "")
-            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-40:]
-            acc[(short, r.get("Counter_Name"))].append((int(r.get("Dispatch_Id", 0)), float(r.get("Counter_Value", 0))))
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-44:]
+            acc[(short, r.get("Counter_Name"))][int(r.get("Dispatch_Id", 0))] += float(r.get("Counter_Value", 0))
     print("==", os.path.basename(d))
-    for (k, c), v in sorted(acc.items()):
-        if not k.startswith("k_"): continue
-        per = collections.defaultdict(float)
-        for did, val in v: per[did] += val
-        vals = [per[k2] for k2 in sorted(per)]
-        tail = vals[len(vals)//2:]            # timed half (after warm-up)
-        print(f"  {k:32s} {c:24s} n={len(vals):3d} mean_all={sum(vals)/len(vals):.4e} mean_tail={sum(tail)/len(tail):.4e}")
-
-# traffic per env-step of the fused kernel (timed launches), for bench.py's roofline.traffic
-import json
-def _mean(d, kernel, counter):
-    acc = collections.defaultdict(float)
-    for f in glob.glob(os.path.join(root, d, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                acc[int(r["Dispatch_Id"])] += float(r["Counter_Value"])
-    vals = [acc[k] for k in sorted(acc)]
-    vals = vals[1:]                       # drop the warm-up launch
-    return (sum(vals) / len(vals), int(list(csv.DictReader(open(f)))[0]["Grid_Size"])) if vals else (None, 0)
-try:
-    fetch, _ = _mean("pass1", "k_fused_rollout", "FETCH_SIZE")
-    write, _ = _mean("pass2", "k_fused_rollout", "WRITE_SIZE")
-    if fetch is not None and write is not None and len(sys.argv) > 3:
-        boards, steps_per_launch = int(sys.argv[2]), int(sys.argv[3])
-        per_launch = (fetch + write) * 1024.0 + 16.0 * boards  # + the half of the 32 B/lane wide loads FETCH_SIZE misses on gfx950
-        out = {"bytes_per_env_step": per_launch / (boards * steps_per_launch),
-               "fetch_kb_per_launch": fetch, "write_kb_per_launch": write, "boards": boards,
-               "steps_per_launch": steps_per_launch,
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --cpu-seconds 0`; "
-                         "(FETCH_SIZE + WRITE_SIZE) * 1024 + 16 B/board for the wide board+aux loads that gfx950 "
-                         "counts at half"}
-        print("TRAFFIC_JSON " + json.dumps(out))
-except Exception as e:  # summary only
-    print("traffic: n/a", e)
+    for (k, c), per in sorted(acc.items()):
+        if "k_fused_rollout" not in k and "k_table" not in k:
+            continue
+        vals = [per[i] for i in sorted(per)]
+        tail = vals[-timed:] if (timed and "k_fused_rollout" in k) else vals
+        mean = sum(tail) / len(tail)
+        line = f"  {k:40s} {c:36s} n={len(vals):3d} mean_timed={mean:.4e}"
+        if steps_per_dispatch and "k_fused_rollout" in k:
+            line += f"  per_env_step={mean / steps_per_dispatch:.4f}"
+            summary[c] = mean / steps_per_dispatch
+        print(line)
+if bench and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+    cfg = bench["config"]
+    S = cfg["steps_per_launch"]
+    # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 counts wide coalesced streaming reads at half:
+    # the 32 B/lane/launch of board + aux loads -> + 16 B per board per launch
+    per_step = (summary["FETCH_SIZE"] + summary["WRITE_SIZE"]) * 1024.0 + 16.0 / S
+    out = {"bytes_per_env_step": per_step,
+           "fetch_bytes_per_env_step": summary["FETCH_SIZE"] * 1024.0,
+           "write_bytes_per_env_step": summary["WRITE_SIZE"] * 1024.0,
+           "requests_per_env_step": {k: v for k, v in summary.items() if k.startswith("TCC_")},
+           "config": {"boards": cfg["boards_per_gpu"], "steps_per_launch": S,
+                      "cap_log2": cfg["table_capacity_log2"],
+                      "board_size": 4 if "4x4" in cfg["workload"] else 5, "eps": cfg["epsilon"],
+                      "strict_td": cfg["td_write"] != "store (last writer wins)"},
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `"
+                     + open(os.path.join(root, "command.txt")).read().strip() + "`, timed dispatches only; "
+                     "(FETCH_SIZE + WRITE_SIZE) * 1024 + 16 B/board/launch for the wide board+aux loads "
+                     "that gfx950 counts at half"}
+    print("TRAFFIC_JSON " + json.dumps(out))
