@@ -106,12 +106,11 @@ _SIGNATURES = {
                                           C.c_void_p]),
     "q2048_table_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_void_p]),
     "q2048_table_count": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "q2048_det_phase1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
-                                   C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32,
-                                   C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]),
-    "q2048_det_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                  C.c_int, C.c_double, C.c_void_p, C.c_void_p]),
+    "q2048_det_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "q2048_det_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                    C.c_int64, C.c_double, C.c_double, C.c_double, C.c_uint64,
+                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "q2048_legal_moves": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "q2048_encode_onehot": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "q2048_rt_choose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_uint64,

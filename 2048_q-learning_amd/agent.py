@@ -291,36 +291,31 @@ class BatchedQLearningAgent:
         self.ctr += int(steps)
 
     def deterministic_rollout(self, env: BatchedGame2048Env, steps: int) -> None:
-        """Reproducible shared-table training, one step per iteration: every env acts on the
-        table as it is at the start of the step, then the updates are grouped by (state, action)
-        and applied in env order.  The result does not depend on how lanes are scheduled and
-        equals the reference agent fed the same transitions in env order (parity at any B);
-        it is several launches and two sorts per step, so use `fused_rollout` for speed."""
+        """Reproducible shared-table training (q2048_det_rollout): per step every env acts on the
+        table as it is at the start of the step, the updates are sorted by (row, action) on the
+        device and each group is applied in env order.  The result does not depend on how lanes
+        are scheduled and equals the reference agent fed the same transitions in env order
+        (parity at any B).  Several launches and a radix sort per step: `fused_rollout` is the
+        fast path, this one is the yard-stick."""
         if env.device != self.device or env.board_size != self.board_size:
             raise ValueError("env and agent do not match")
         if (env.seed, env.env_id0, env.ctr) != (self.seed, self.env_id0, self.ctr):
             raise ValueError("env and agent must share seed, env_id0 and step counter")
-        B, words = env.num_envs, (1 if self.board_size == 4 else 2)
-        keys = torch.empty((B, words), dtype=torch.int64, device=self.device)
-        acts = torch.empty(B, dtype=torch.uint8, device=self.device)
-        target = torch.empty(B, dtype=torch.float64, device=self.device)
-        L, stream = N.lib(), _stream(self.device)
-        for _ in range(int(steps)):
-            N.check(L.q2048_det_phase1(
-                _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, B,
-                self.board_size, float(self.epsilon), float(self.gamma), self.seed, self.env_id0,
-                self.ctr & 0xFFFFFFFF, self.flags, _ptr(keys), _ptr(acts), _ptr(target),
-                _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status), stream), "det_phase1")
-            # stable sorts, least significant criterion first: env order survives inside a group
-            order = torch.argsort(acts, stable=True)
-            for w in reversed(range(words)):
-                order = order[torch.argsort(keys[order, w], stable=True)]
-            ks, as_, ts = keys[order].contiguous(), acts[order].contiguous(), target[order].contiguous()
-            N.check(L.q2048_det_apply(_ptr(self.table), self.capacity_log2, _ptr(ks), _ptr(as_),
-                                      _ptr(ts), B, words, float(self.lr), _ptr(self.status), stream),
-                    "det_apply")
-            env.ctr += 1
-            self.ctr += 1
+        B, L = env.num_envs, N.lib()
+        need = int(L.q2048_det_workspace_bytes(B, self.capacity_log2))
+        if need < 0:
+            N.check(need, "det_workspace_bytes")
+        ws = getattr(self, "_det_ws", None)
+        if ws is None or ws.numel() < need + 256:
+            ws = self._det_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = (ws.data_ptr() + 255) & ~255                       # the workspace is 256-byte aligned
+        N.check(L.q2048_det_rollout(
+            _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, B, self.board_size,
+            int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed, self.env_id0,
+            self.ctr & 0xFFFFFFFF, self.flags | env.env_flags, _ptr(self.stats_i), _ptr(self.stats_f),
+            _ptr(self.status), base, need, _stream(self.device)), "det_rollout")
+        env.ctr += int(steps)
+        self.ctr += int(steps)
 
     # -- statistics / table access ---------------------------------------------------------
     def stats(self, reset: bool = False) -> dict:
@@ -514,6 +509,8 @@ class BatchedRowTupleAgent:
     def fused_rollout(self, env: BatchedGame2048Env, steps: int) -> None:
         if env.board_size != 4 or env.device != self.device:
             raise ValueError("the row-tuple learner needs a 4x4 env on the same device")
+        if env.env_flags:
+            raise ValueError("env profiles are supported by the hash-table agent only")
         if (env.seed, env.env_id0, env.ctr) != (self.seed, self.env_id0, self.ctr):
             raise ValueError("env and agent must share seed, env_id0 and step counter")
         N.check(N.lib().q2048_rt_fused_rollout(

@@ -15,6 +15,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "q2048.h"
 #include "q2048_core5.hpp"
 
@@ -449,6 +451,50 @@ __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux*
   store_board(boards, i, B, b, st);
 }
 
+// The 4x4 single-step kernel of the 4-call API, software-pipelined.  With one board per thread the
+// whole device loads, then computes (~520 VALU per board), then stores, in lockstep: at 1 Mi boards
+// the grid is exactly two such rounds and neither the memory system nor the VALUs are busy for
+// more than half of the time.  Here a thread walks `boards / (grid * 256)` boards and requests
+// board, aux and action of the next one before it computes the current one, so loads of one
+// iteration fly under the arithmetic of another.
+template <int ENV>
+__global__ __launch_bounds__(kBlock) void k_env_step4_pipelined(
+    uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, uint64_t seed,
+    uint64_t env_id0, uint32_t ctr, float* reward, uint8_t* done, uint8_t* max_l2, uint32_t* status) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  uint4 bv = reinterpret_cast<const uint4*>(boards)[i];
+  uint4 av = reinterpret_cast<const uint4*>(aux)[i];
+  uint32_t act = actions[i];
+  for (;;) {
+    const int64_t nxt = i + stride;
+    uint4 bn = bv, an = av;
+    uint32_t actn = 0;
+    if (nxt < B) {                                        // in flight during the arithmetic below
+      bn = reinterpret_cast<const uint4*>(boards)[nxt];
+      an = reinterpret_cast<const uint4*>(aux)[nxt];
+      actn = actions[nxt];
+    }
+    if (act > 3u) {  // rejected, never masked (Game2048_env.py:56-60 would mis-rotate)
+      atomicOr(status, Q2048_STATUS_BAD_ACTION);
+      reward[i] = 0.f; done[i] = 0; max_l2[i] = 0;
+    } else {
+      Board b{bv.x, bv.y, bv.z, bv.w};
+      Aux a = words_to_aux(Words4{av.x, av.y, av.z, av.w});
+      const Draws x = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamStep);
+      Draws y{0u, 0u, 0u, 0u};
+      if constexpr ((ENV & kEnvDqn) != 0) y = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamOver);
+      const StepOut o = env_step_profile<ENV>(b, a, (int)act, x.x2, x.x3, y.x0, y.x1);
+      reinterpret_cast<uint4*>(boards)[i] = make_uint4(b.r0, b.r1, b.r2, b.r3);
+      st_aux(aux, i, a);
+      reward[i] = o.reward; done[i] = o.done; max_l2[i] = o.max_log2;
+    }
+    if (nxt >= B) break;
+    i = nxt; bv = bn; av = an; act = actn;
+  }
+}
+
 // legal-move mask (mainDQL_CNN_step2.py:168-174): four trial moves per lane, nothing stored back
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_legal_moves(const uint8_t* boards, int64_t B, uint8_t* mask_out) {
@@ -732,19 +778,17 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
 }
 
 // ---------------------------------------------------------------------------------------------
-// deterministic mode: phase 1 (act on the step-start table, emit key / action / target) and
-// phase 2 (apply the updates grouped by (key, action), env order inside a group)
+// deterministic mode.  One step = phase 1 (every env acts on the table as it is at the start of
+// the step and emits where its update goes and its TD target), a stable radix sort of the updates
+// by (row slot, action) -- rocPRIM's device radix sort over the cap_log2 + 3 bits that are
+// populated: a standard primitive, not hand-written here -- and phase 2 (each (slot, action) group
+// applies its updates in env order).  Nothing in it depends on how lanes are scheduled.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void emit_key(u64* out, int64_t i, const Geo<4>::Key& k) { out[i] = k.k0; }
-__device__ __forceinline__ void emit_key(u64* out, int64_t i, const Geo<5>::Key& k) {
-  out[2 * i] = k.k0; out[2 * i + 1] = k.k1;
-}
-
-template <int N>
+template <int N, int ENV>
 __global__ __launch_bounds__(kBlock) void k_det_phase1(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
-    uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* keys_out, uint8_t* actions_out,
-    double* target_out, int64_t* stats_i, double* stats_f, uint32_t* status) {
+    uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, uint32_t* env_out,
+    double* target_out, int drop_bit, int64_t* stats_i, double* stats_f, uint32_t* status) {
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
   stats_clear(bs);
@@ -761,19 +805,22 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
     if (slot_s < 0 && slot_s != kNoSlot) slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
     if (slot_s < 0) { dropped = true; atomicOr(status, Q2048_STATUS_TABLE_FULL); }
     const Draws x = draws(seed, id, ctr, kStreamStep);
+    Draws y{0u, 0u, 0u, 0u};
+    if constexpr ((ENV & kEnvDqn) != 0) y = draws(seed, id, ctr, kStreamOver);
     bool explored;
     const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);     // main.py:92
-    const StepOut o = env_step(b, a, act, x.x2, x.x3);                                  // :93
+    const StepOut o = env_step_profile<ENV>(b, a, act, x.x2, x.x3, y.x0, y.x1);         // :93
     const auto key_n = state_key(b, salt, status);
     const int64_t slot_n = probe_find(table, mask, key_n, qn, ins_n);                   // :41
     if (slot_n < 0 && slot_n != kNoSlot) probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
-    emit_key(keys_out, i, key_s);
-    actions_out[i] = (uint8_t)(dropped ? 0xFF : act);      // 0xFF: no row, phase 2 skips it
+    // the group of this update: (slot of s, action); a dropped one sorts behind every group
+    group_out[i] = dropped ? (1ull << drop_bit) : (((u64)slot_s << 2) | (u64)act);
+    env_out[i] = (uint32_t)i;
     target_out[i] = (double)o.reward +
                     (gamma * (double)max4(qn.q0, qn.q1, qn.q2, qn.q3) * (o.done ? 0.0 : 1.0));  // :42
     if (o.done) {
       episode_stats(bs, a, o.max_log2);
-      begin_episode(b, a, seed, id);
+      begin_episode(b, a, seed, id, (ENV & kEnvResetShaping) != 0);
     }
     st_aux(aux, i, a);
     const uint32_t n_valid = wave_count(o.valid != 0), n_explore = wave_count(explored),
@@ -793,30 +840,69 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
   stats_flush(bs, stats_i, stats_f);
 }
 
-template <int WORDS>
-__global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, u64 mask, const u64* keys,
-                                                      const uint8_t* actions, const double* target,
-                                                      int64_t B, double lr, uint32_t* status) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= B) return;
-  typename Geo<WORDS == 1 ? 4 : 5>::Key key;
-  key.k0 = keys[i * WORDS];
-  if constexpr (WORDS == 2) key.k1 = keys[i * 2 + 1];
-  const uint32_t act = actions[i];
-  auto same_group = [&](int64_t j) {
-    bool eq = keys[j * WORDS] == key.k0 && actions[j] == act;
-    if constexpr (WORDS == 2) eq = eq && keys[j * 2 + 1] == key.k1;
-    return eq;
-  };
-  if (act > 3u || (i > 0 && same_group(i - 1))) return;   // not the head of a (key, action) group
-  Row r;
-  bool made;
-  const int64_t slot = probe_find(table, mask, key, r, made);
-  if (slot < 0) { atomicOr(status, Q2048_STATUS_TABLE_FULL); return; }
-  float q = row_get(r, (int)act);
-  for (int64_t j = i; j < B && same_group(j); ++j)          // Agent/main.py:43, in env order
-    q = (float)((double)q + lr * (target[j] - (double)q));
-  table[slot].q[act] = q;
+// Phase 2 on the sorted updates: group[j] = (slot << 2) | action ascending, env order inside a
+// group (the sort is stable and phase 1 wrote envs in order).  Agent/main.py:43 is the affine map
+// q -> (1 - lr) q + lr * target; a group applies its maps in env order, in double precision, and
+// rounds to float32 once -- for one update that is exactly td_value().  The first lane of a group
+// walks up to kDetSerial updates itself; longer groups (the handful of states many envs share,
+// e.g. right after a reset) go on a list for k_det_apply_long, one wave per group.
+constexpr int kDetSerial = 32;
+__global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u64* group,
+                                                      const uint32_t* env, const double* target,
+                                                      int64_t B, double lr, int drop_bit, u64* longs) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  const u64 g = group[j];
+  if ((g >> drop_bit) != 0ull || (j > 0 && group[j - 1] == g)) return;   // dropped, or not a head
+  int len = 1;
+  while (len <= kDetSerial && j + len < B && group[j + len] == g) ++len;
+  if (len > kDetSerial) {            // at most B / 33 such groups: the list cannot overflow
+    longs[1ull + atomicAdd(&longs[0], 1ull)] = (u64)j;
+    return;
+  }
+  float* cell = &table[g >> 2].q[g & 3ull];
+  double q = (double)*cell;
+  for (int k = 0; k < len; ++k) q = q + lr * (target[env[j + k]] - q);  // Agent/main.py:43
+  *cell = (float)q;
+}
+
+// One wave per long group: every lane composes the affine maps of a contiguous share of the
+// group, (a, b) meaning q -> a q + b, the shares are composed in order with a shuffle tree, and
+// lane 0 applies the result.  The tree depends only on the group's length: deterministic.
+__global__ __launch_bounds__(kBlock) void k_det_apply_long(q2048_slot* table, const u64* group,
+                                                           const uint32_t* env, const double* target,
+                                                           int64_t B, double lr, const u64* longs) {
+  const u64 n_long = longs[0];
+  const uint32_t lane = threadIdx.x & 63u;
+  const u64 waves = (u64)gridDim.x * (kBlock / 64);
+  for (u64 w = (u64)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n_long; w += waves) {
+    const int64_t start = (int64_t)longs[1ull + w];
+    const u64 g = group[start];
+    int64_t len = 0;                                     // wave-uniform search for the group's end
+    for (;;) {
+      const int64_t pos = start + len + (int64_t)lane;
+      const u64 same = __ballot(pos < B && group[pos] == g);
+      if (same != ~0ull) { len += (int64_t)(__ffsll((long long)~same) - 1); break; }
+      len += 64;
+    }
+    const int64_t share = (len + 63) / 64;
+    const int64_t lo = start + (int64_t)lane * share;
+    const int64_t hi = lo + share < start + len ? lo + share : start + len;
+    double a = 1.0, b = 0.0;                             // identity for lanes beyond the group
+    for (int64_t k = lo; k < hi; ++k) {
+      a = a * (1.0 - lr);
+      b = b * (1.0 - lr) + lr * target[env[k]];
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {                   // (lane + d) after lane: a_hi (a q + b) + b_hi
+      const double a_hi = __shfl_down(a, d), b_hi = __shfl_down(b, d);
+      if ((lane & (2u * d - 1u)) == 0u) { b = a_hi * b + b_hi; a = a_hi * a; }
+    }
+    if (lane == 0u) {
+      float* cell = &table[g >> 2].q[g & 3ull];
+      *cell = (float)(a * (double)*cell + b);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1188,6 +1274,22 @@ static int env_step_impl(uint8_t* boards, q2048_aux* aux, const uint8_t* actions
   if (!boards || !aux || !actions || !reward || !done || !max_log2 || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
+  if (n == 4 && draw_pos == nullptr) {
+    // pipelined kernel: 4 boards per thread once the batch fills the device (4 blocks of 4 waves
+    // per CU keep 4 loads per SIMD lane-slot in flight); experiment bits 8..11 override the count
+    const int64_t per_thread = ((flags >> 8) & 15u) ? (int64_t)((flags >> 8) & 15u) : 4;
+    int64_t blocks = (B + kBlock * per_thread - 1) / (kBlock * per_thread);
+    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
+    if (flags & Q2048_FLAG_ENV_DQN)
+      hipLaunchKernelGGL(k_env_step4_pipelined<kEnvDqn>, dim3((unsigned)blocks), dim3(kBlock), 0,
+                         (hipStream_t)stream, boards, aux, actions, B, seed, env_id0, ctr, reward, done,
+                         max_log2, status);
+    else
+      hipLaunchKernelGGL(k_env_step4_pipelined<0>, dim3((unsigned)blocks), dim3(kBlock), 0,
+                         (hipStream_t)stream, boards, aux, actions, B, seed, env_id0, ctr, reward, done,
+                         max_log2, status);
+    return launch_status();
+  }
   Q2048_LAUNCH_ENV(k_env_step, flags & Q2048_FLAG_ENV_DQN, n, B, stream, boards, aux, actions, B, seed,
                    env_id0, ctr, reward, done, max_log2, status, draw_pos, draw_val, draw_opos,
                    draw_oval, draw_stride);
@@ -1309,40 +1411,73 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
   return launch_status();
 }
 
-int q2048_det_phase1(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2, int64_t B, int n,
-                     double eps, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr,
-                     uint32_t flags, uint64_t* keys_out, uint8_t* actions_out, double* target_out,
-                     int64_t* stats_i, double* stats_f, uint32_t* status, void* stream) {
-  if (int e = check_batch(B, n)) return e;
-  if (int e = check_table(table, cap_log2)) return e;
-  if (!boards || !aux || !keys_out || !actions_out || !target_out || !status) return Q2048_ERR_NULL;
-  if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
-  if (!(eps >= 0.0 && eps <= 1.0) || !(gamma == gamma)) return Q2048_ERR_RANGE;
-  if (B == 0) return Q2048_OK;
-  Q2048_LAUNCH(k_det_phase1, n, B, stream, boards, aux, table, (u64)((1ull << cap_log2) - 1ull), B, eps,
-               gamma, seed, env_id0, ctr, flags, reinterpret_cast<u64*>(keys_out), actions_out,
-               target_out, stats_i, stats_f, status);
-  return launch_status();
+// workspace of q2048_det_rollout: double-buffered (group, env) pairs, targets, the list of long
+// groups, rocPRIM's temporary storage; every part 256-byte aligned
+struct DetLayout { size_t group[2], env[2], target, longs, sort, sort_bytes, total; };
+static int det_layout(int64_t B, int cap_log2, DetLayout& L) {
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t at = 0;
+  for (int k = 0; k < 2; ++k) { L.group[k] = at; at += up((size_t)B * 8); }
+  for (int k = 0; k < 2; ++k) { L.env[k] = at; at += up((size_t)B * 4); }
+  L.target = at; at += up((size_t)B * 8);
+  L.longs = at; at += up(((size_t)B / (kDetSerial + 1) + 2) * 8);
+  L.sort_bytes = 0;
+  if (rocprim::radix_sort_pairs<rocprim::default_config, u64*, u64*, uint32_t*, uint32_t*>(
+          nullptr, L.sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)B, 0u,
+          (unsigned)(cap_log2 + 3), (hipStream_t)0) != hipSuccess)
+    return Q2048_ERR_LAUNCH;
+  L.sort = at; at += up(L.sort_bytes);
+  L.total = at;
+  return Q2048_OK;
 }
 
-int q2048_det_apply(q2048_slot* table, int cap_log2, const uint64_t* keys_sorted,
-                    const uint8_t* actions_sorted, const double* target_sorted, int64_t B,
-                    int key_words, double lr, uint32_t* status, void* stream) {
+int64_t q2048_det_workspace_bytes(int64_t B, int cap_log2) {
+  if (B < 0 || B > 0x7fffffffll || cap_log2 < 4 || cap_log2 > 40) return Q2048_ERR_SIZE;
+  DetLayout L;
+  if (int e = det_layout(B > 0 ? B : 1, cap_log2, L)) return e;
+  return (int64_t)L.total;
+}
+
+int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2, int64_t B, int n,
+                      int64_t steps, double eps, double lr, double gamma, uint64_t seed,
+                      uint64_t env_id0, uint32_t ctr0, uint32_t flags, int64_t* stats_i,
+                      double* stats_f, uint32_t* status, void* workspace, int64_t workspace_bytes,
+                      void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (B > 0x7fffffffll) return Q2048_ERR_SIZE;                       // env indices are 32-bit here
   if (int e = check_table(table, cap_log2)) return e;
-  if (!keys_sorted || !actions_sorted || !target_sorted || !status) return Q2048_ERR_NULL;
-  if (B < 0 || (key_words != 1 && key_words != 2)) return Q2048_ERR_SIZE;
-  if (!(lr == lr)) return Q2048_ERR_RANGE;
-  if (B == 0) return Q2048_OK;
+  if (!boards || !aux || !status || !workspace) return Q2048_ERR_NULL;
+  if (!aligned16(boards) || !aligned16(aux) || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return Q2048_ERR_ALIGN;
+  if (steps < 0 || steps > (1 << 30)) return Q2048_ERR_SIZE;
+  if (!(eps >= 0.0 && eps <= 1.0) || !(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
+  if (B == 0 || steps == 0) return Q2048_OK;
+  DetLayout L;
+  if (int e = det_layout(B, cap_log2, L)) return e;
+  if (workspace_bytes < (int64_t)L.total) return Q2048_ERR_SIZE;
+  char* ws = static_cast<char*>(workspace);
+  u64* group[2] = {reinterpret_cast<u64*>(ws + L.group[0]), reinterpret_cast<u64*>(ws + L.group[1])};
+  uint32_t* env[2] = {reinterpret_cast<uint32_t*>(ws + L.env[0]), reinterpret_cast<uint32_t*>(ws + L.env[1])};
+  double* target = reinterpret_cast<double*>(ws + L.target);
+  u64* longs = reinterpret_cast<u64*>(ws + L.longs);
+  const hipStream_t s = (hipStream_t)stream;
   const u64 mask = (1ull << cap_log2) - 1ull;
-  if (key_words == 1)
-    hipLaunchKernelGGL(k_det_apply<1>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
-                       mask, reinterpret_cast<const u64*>(keys_sorted), actions_sorted, target_sorted, B,
-                       lr, status);
-  else
-    hipLaunchKernelGGL(k_det_apply<2>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table,
-                       mask, reinterpret_cast<const u64*>(keys_sorted), actions_sorted, target_sorted, B,
-                       lr, status);
-  return launch_status();
+  const int drop_bit = cap_log2 + 2;
+  for (int64_t t = 0; t < steps; ++t) {
+    Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
+                     ctr0 + (uint32_t)t, flags, group[0], env[0], target, drop_bit, stats_i, stats_f,
+                     status);
+    if (hipMemsetAsync(longs, 0, 8, s) != hipSuccess) return Q2048_ERR_LAUNCH;
+    size_t sort_bytes = L.sort_bytes;
+    if (rocprim::radix_sort_pairs(ws + L.sort, sort_bytes, group[0], group[1], env[0], env[1], (size_t)B,
+                                  0u, (unsigned)(drop_bit + 1), s) != hipSuccess)
+      return Q2048_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_det_apply, dim3(grid_for(B)), dim3(kBlock), 0, s, table, group[1], env[1], target,
+                       B, lr, drop_bit, longs);
+    hipLaunchKernelGGL(k_det_apply_long, dim3(256), dim3(kBlock), 0, s, table, group[1], env[1], target, B,
+                       lr, longs);
+    if (int e = launch_status()) return e;
+  }
+  return Q2048_OK;
 }
 
 int q2048_legal_moves(const uint8_t* boards, int64_t B, int n, uint8_t* mask_out, void* stream) {

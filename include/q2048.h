@@ -240,24 +240,27 @@ int q2048_fused_rollout_log(uint8_t *boards, q2048_aux *aux, q2048_slot *table, 
                             q2048_episode *log, int64_t log_capacity, uint64_t *log_count,
                             void *stream);
 
-/* Deterministic mode (reproducible shared-table runs; slower, one step per call).  A step is
- * split in two so that no result depends on the order in which lanes run:
- *   q2048_det_phase1  every env chooses on, steps, and reads max Q(s') from the table as it is at
- *                     the start of the step (phase 1 writes no Q value; it creates the rows of s
- *                     and s' like update_q_value does, Agent/main.py:41-43) and emits per env its
- *                     state key (key_words = 1 for n = 4, 2 for n = 5), action and TD target
- *                     reward + gamma * max Q(s') * (1 - done) (:42);
- *   q2048_det_apply   takes those arrays SORTED by (key, action) with env order kept inside a
- *                     group (the caller sorts -- any stable sort) and applies
- *                     Q[s][a] += lr * (target - Q[s][a]) (:43) sequentially within each group.
- * The result equals the reference agent fed the same transitions in env order, for any B. */
-int q2048_det_phase1(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2, int64_t B,
-                     int n, double eps, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr,
-                     uint32_t flags, uint64_t *keys_out, uint8_t *actions_out, double *target_out,
-                     int64_t *stats_i, double *stats_f, uint32_t *status, void *stream);
-int q2048_det_apply(q2048_slot *table, int cap_log2, const uint64_t *keys_sorted,
-                    const uint8_t *actions_sorted, const double *target_sorted, int64_t B,
-                    int key_words, double lr, uint32_t *status, void *stream);
+/* Deterministic mode: reproducible shared-table training at any B (the default rollout is
+ * lock-free and depends on scheduling wherever lanes share a state).  Per step:
+ *   phase 1  every env chooses on, steps, and reads max Q(s') from the table as it is at the
+ *            START of the step (phase 1 writes no Q value; it creates the rows of s and s' like
+ *            update_q_value does, Agent/main.py:41-43) and emits its update: (row slot, action)
+ *            and the TD target reward + gamma * max Q(s') * (1 - done) (:42);
+ *   sort     the updates are sorted by (slot, action) on the device, env order kept inside a group;
+ *   phase 2  every group applies Q[s][a] += lr * (target - Q[s][a]) (:43) in env order (double
+ *            precision inside a group, one rounding to float32; for a group of one that is the
+ *            reference update exactly).
+ * The result equals the reference agent fed the step's transitions in env order against the
+ * step-start table, for any B, bit-identically from run to run.  `steps` steps per call, draws of
+ * counter ctr0 + t; flags as q2048_fused_rollout (TD_CAS / PLAY_ONLY have no meaning here).
+ * `workspace`: caller-owned device scratch of q2048_det_workspace_bytes(B, cap_log2) bytes,
+ * 256-byte aligned (B < 2^31). */
+int64_t q2048_det_workspace_bytes(int64_t B, int cap_log2);
+int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2, int64_t B,
+                      int n, int64_t steps, double eps, double lr, double gamma, uint64_t seed,
+                      uint64_t env_id0, uint32_t ctr0, uint32_t flags, int64_t *stats_i,
+                      double *stats_f, uint32_t *status, void *workspace, int64_t workspace_bytes,
+                      void *stream);
 
 /* Placement probe (no reference counterpart): `lanes` lanes each issue `steps` scattered
  * device-scope atomic ORs of 0 on key words of the table -- the write-side request pattern of

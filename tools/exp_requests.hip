@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #define CK(x)                                                                        \
   do {                                                                               \
@@ -46,7 +47,7 @@ enum { kLoad = 1, kCas = 2, kStore = 4, kCasAlways = 8, kStore16 = 16, kStore32 
 
 __global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, int64_t lanes, int steps,
                                                   int what, int work, uint32_t ctr0, uint32_t* sink,
-                                                  uint32_t* bitmap) {
+                                                  uint32_t* bitmap, int flavor) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= lanes) return;
   uint32_t acc = (uint32_t)i;
@@ -71,10 +72,29 @@ __global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, in
     }
     if ((what & kLoad) || ((what & kLoadIfSet) && bit_set)) {
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 v;
-      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(&table[at]) : "memory");
+      u32x4 v, v2 = {0u, 0u, 0u, 0u};
+      const Slot* p = &table[at];
+      const char* p2 = reinterpret_cast<const char*>(p) + 16;
+      // cache-policy flavours of the probe load (flavor & 7) and, with flavor & 8, the second half
+      // of the row in the same round trip
+#define LD(BITS)                                                                                   \
+  if (flavor & 8)                                                                                  \
+    asm volatile("global_load_dwordx4 %0, %2, off " BITS "\n\tglobal_load_dwordx4 %1, %3, off " BITS \
+                 "\n\ts_waitcnt vmcnt(0)" : "=&v"(v), "=&v"(v2) : "v"(p), "v"(p2) : "memory");     \
+  else                                                                                             \
+    asm volatile("global_load_dwordx4 %0, %1, off " BITS "\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+      switch (flavor & 7) {
+        case 0: LD("sc1") break;
+        case 1: LD("") break;
+        case 2: LD("nt") break;
+        case 3: LD("sc0 sc1") break;
+        case 4: LD("sc0 sc1 nt") break;
+        case 5: LD("sc1 nt") break;
+        default: LD("sc0") break;
+      }
+#undef LD
       seen = (uint64_t)v.x | ((uint64_t)v.y << 32);
-      acc ^= v.z;
+      acc ^= v.z ^ v2.x;
     }
     if ((what & kCasAlways) || ((what & kCas) && seen == 0ull)) {
       const uint64_t r = atomicCAS(&table[at].key, 0ull, key);
@@ -108,6 +128,8 @@ int main(int argc, char** argv) {
   const int lanes_log2 = argc > 2 ? std::atoi(argv[2]) : 20;
   const int steps = argc > 3 ? std::atoi(argv[3]) : 64;
   const int alloc_log2 = argc > 4 ? std::atoi(argv[4]) : cap_log2;   // allocate more than is used
+  const char* only = argc > 5 ? argv[5] : nullptr;                   // run only combos whose name contains this
+  const int alloc_mode = argc > 6 ? std::atoi(argv[6]) : 0;          // 0 hipMalloc, 1 fine-grained, 3 uncached
   if (cap_log2 < 10 || cap_log2 > 32 || alloc_log2 < cap_log2 || alloc_log2 > 32 || lanes_log2 < 6 || lanes_log2 > 24 || steps < 1 || steps > 4096) {
     std::fprintf(stderr, "bad arguments\n");
     return 2;
@@ -117,14 +139,15 @@ int main(int argc, char** argv) {
   Slot* table;
   uint32_t* sink;
   uint32_t* bitmap;
-  CK(hipMalloc(&table, (1ull << alloc_log2) * sizeof(Slot)));
+  if (alloc_mode == 0) CK(hipMalloc(&table, (1ull << alloc_log2) * sizeof(Slot)));
+  else CK(hipExtMallocWithFlags(reinterpret_cast<void**>(&table), (1ull << alloc_log2) * sizeof(Slot), (unsigned)alloc_mode));
   CK(hipMalloc(&bitmap, cap / 8));
   CK(hipMalloc(&sink, 4));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const unsigned grid = (unsigned)((lanes + 255) / 256);
-  struct { const char* name; int what; } combos[] = {
+  struct { const char* name; int what; int flavor = 0; } combos[] = {
       {"none", 0}, {"load", kLoad}, {"store", kStore}, {"cas(always)", kCasAlways},
       {"load+cas", kLoad | kCas}, {"load+store", kLoad | kStore},
       {"load+cas+store", kLoad | kCas | kStore}, {"cas(always)+store", kCasAlways | kStore},
@@ -138,23 +161,32 @@ int main(int argc, char** argv) {
       {"bmload+bmor+store64", kBmLoad | kBmOr | kStore64},
       {"bmload+bmor+store", kBmLoad | kBmOr | kStore},
       {"bmor(always)+store32", kBmOrAlways | kStore32},
-      {"bmload+bmor+load(if set)+store32", kBmLoad | kBmOr | kLoadIfSet | kStore32}};
-  std::printf("{\"alloc_log2\": %d, \"cap_log2\": %d, \"lanes\": %lld, \"steps\": %d, \"unit\": \"us per step per 2^20 lanes\", \"rows\": [\n",
-              alloc_log2, cap_log2, (long long)lanes, steps);
+      {"bmload+bmor+load(if set)+store32", kBmLoad | kBmOr | kLoadIfSet | kStore32},
+      {"load[plain]", kLoad, 1}, {"load[nt]", kLoad, 2}, {"load[sc0 sc1]", kLoad, 3},
+      {"load[sc0 sc1 nt]", kLoad, 4}, {"load[sc1 nt]", kLoad, 5}, {"load[sc0]", kLoad, 6},
+      {"load32[sc1]", kLoad, 8}, {"load32[nt]", kLoad, 8 | 2}, {"load32[sc0 sc1]", kLoad, 8 | 3},
+      {"load32[sc0 sc1 nt]", kLoad, 8 | 4},
+      {"load[nt]+cas+store", kLoad | kCas | kStore, 2}, {"load[sc0 sc1]+cas+store", kLoad | kCas | kStore, 3},
+      {"load[sc0 sc1 nt]+cas+store", kLoad | kCas | kStore, 4}, {"load[sc1 nt]+cas+store", kLoad | kCas | kStore, 5},
+      {"load[nt]+store", kLoad | kStore, 2}, {"load[sc0 sc1]+store", kLoad | kStore, 3},
+      {"load32[sc0 sc1]+cas+store", kLoad | kCas | kStore, 8 | 3}};
+  std::printf("{\"alloc_mode\": %d, \"alloc_log2\": %d, \"cap_log2\": %d, \"lanes\": %lld, \"steps\": %d, \"unit\": \"us per step per 2^20 lanes\", \"rows\": [\n",
+              alloc_mode, alloc_log2, cap_log2, (long long)lanes, steps);
   bool first = true;
   for (auto& c : combos) {
+    if (only != nullptr && std::strstr(c.name, only) == nullptr) continue;
     for (int work : {0}) {
       CK(hipMemsetAsync(table, 0, cap * sizeof(Slot), 0));       // every run starts on an empty table
       CK(hipMemsetAsync(bitmap, 0, cap / 8, 0));
       uint32_t ctr = 0;
       hipLaunchKernelGGL(k_requests, dim3(grid), dim3(256), 0, 0, table, cap - 1, lanes, steps, c.what,
-                         work, ctr, sink, bitmap);                // warm-up (fills steps*lanes keys)
+                         work, ctr, sink, bitmap, c.flavor);      // warm-up (fills steps*lanes keys)
       ctr += (uint32_t)steps;
       CK(hipEventRecord(e0, 0));
       const int reps = 3;
       for (int r = 0; r < reps; ++r) {
         hipLaunchKernelGGL(k_requests, dim3(grid), dim3(256), 0, 0, table, cap - 1, lanes, steps, c.what,
-                           work, ctr, sink, bitmap);
+                           work, ctr, sink, bitmap, c.flavor);
         ctr += (uint32_t)steps;
       }
       CK(hipEventRecord(e1, 0));
