@@ -553,24 +553,70 @@ def stats_dict(si, sf) -> dict:
     }
 
 
+class _LazyRow:
+    """The 4 Q-values of `agent.q_table[state]` (Agent/main.py:96), read back when first used: the
+    lookup kernel is queued behind the update it follows and its result is fetched at the next
+    synchronisation the loop makes anyway, or on first access.  Behaves like the float64 array the
+    reference's dict returns (indexing, len, iteration, numpy conversion, printing)."""
+
+    __slots__ = ("_io", "_off", "_val", "__weakref__")
+
+    def __init__(self, io: _Staging, off: int):
+        self._io, self._off, self._val = io, off, None
+
+    def _read(self) -> None:
+        if self._val is None:
+            self._val = self._io.np[self._off:self._off + 16].view(np.float32).astype(np.float64)
+
+    def _get(self) -> np.ndarray:
+        if self._val is None:
+            self._io.sync()                      # reads every pending row, this one included
+            self._read()
+        return self._val
+
+    def __array__(self, dtype=None, copy=None):
+        v = self._get()
+        return v if dtype is None else v.astype(dtype)
+
+    shape = property(lambda self: (4,))
+    dtype = property(lambda self: np.dtype(np.float64))
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __repr__(self):
+        return repr(self._get())
+
+    def __str__(self):
+        return str(self._get())
+
+    def __getattr__(self, name):                 # tolist, max, argmax, ... : the array's own
+        return getattr(self._get(), name)
+
+
 class _OneStateTable:
-    """`agent.q_table[state]` / `len(agent.q_table)` of the one-state adapter: the same lookups
-    as `_QTableView`, moved through the adapter's staging buffer (one copy in, one out)."""
+    """`agent.q_table[state]` / `len(agent.q_table)` of the one-state adapter."""
 
     def __init__(self, owner: "QLearningAgent"):
         self._o = weakref.proxy(owner)
 
-    def __getitem__(self, state) -> np.ndarray:
+    def __getitem__(self, state) -> _LazyRow:
         o = self._o
         io, b = o._io, o._b
-        state_to_log2(state, io.np_in[0:16])
-        io.upload(16)
+        off = io.take(32)                                        # [0:16] state in, [16:32] row out
+        state_to_log2(state, io.np[off:off + 16])
         N.check(N.lib().q2048_q_lookup(
-            _ptr(b.table), b.capacity_log2, io.ptr, 1, 4, b.env_id0, b.flags | N.FLAG_SINGLE_ENV,
-            io.ptr + 48, None, _ptr(b.status), _stream(b.device)), "q_lookup")
-        io.download(48, 64)
-        io.sync()
-        return io.np_out[48:64].view(np.float32).astype(np.float64)
+            _ptr(b.table), b.capacity_log2, io.ptr + off, 1, 4, b.env_id0, b.flags | N.FLAG_SINGLE_ENV,
+            io.ptr + off + 16, None, _ptr(b.status), _stream(b.device)), "q_lookup")
+        row = _LazyRow(io, off + 16)
+        io.pending.append(weakref.ref(row))
+        return row
 
     def __len__(self) -> int:
         return self._o._b.table_size()
@@ -578,9 +624,9 @@ class _OneStateTable:
 
 class QLearningAgent:
     """One-state adapter with the reference's exact surface (Agent/main.py:14-57): states are
-    tuples of tuples of raw tile values, actions Python ints.  Every call moves its few bytes
-    through one 64-byte staging buffer: [0:16] state, [16:32] next state, [32] action, [33] done,
-    [36:40] reward, [40] chosen action, [48:64] a Q row."""
+    tuples of tuples of raw tile values, actions Python ints.  Inputs and outputs travel through a
+    ring of pinned host memory that the kernels address directly (`_Staging`): choose_action is
+    one launch and one synchronisation, update_q_value and q_table[state] are one launch each."""
 
     def __init__(self, total_epochs, action_space, learning_rate=0.1, discount_factor=0.9,
                  exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 22,
@@ -607,30 +653,29 @@ class QLearningAgent:
 
     def choose_action(self, state) -> int:
         io, b = self._io, self._b
-        state_to_log2(state, io.np_in[0:16])
-        io.upload(16)
+        off = io.take(32)                                        # [0:16] state in, [16] action out
+        state_to_log2(state, io.np[off:off + 16])
         N.check(N.lib().q2048_q_choose(
-            _ptr(b.table), b.capacity_log2, io.ptr, 1, 4, float(b.epsilon), b.seed, b.env_id0,
-            b.ctr & 0xFFFFFFFF, b.flags, io.ptr + 40, _ptr(b.status), _stream(b.device)), "q_choose")
+            _ptr(b.table), b.capacity_log2, io.ptr + off, 1, 4, float(b.epsilon), b.seed, b.env_id0,
+            b.ctr & 0xFFFFFFFF, b.flags, io.ptr + off + 16, _ptr(b.status), _stream(b.device)), "q_choose")
         b.ctr += 1
-        io.download(40, 41)
         io.sync()
-        return int(io.np_out[40])
+        return int(io.np[off + 16])
 
     def update_q_value(self, state, action, reward, next_state, done) -> None:
         if not 0 <= int(action) <= 3:
             raise ValueError(f"action {action} outside 0..3")
         io, b = self._io, self._b
-        buf = io.np_in
-        state_to_log2(state, buf[0:16])
-        state_to_log2(next_state, buf[16:32])
-        buf[32], buf[33] = int(action), 1 if done else 0
-        buf[36:40].view(np.float32)[0] = reward
-        io.upload(40)
+        off = io.take(48)             # [0:16] state, [16:32] next state, [32] action, [33] done, [36:40] reward
+        buf = io.np
+        state_to_log2(state, buf[off:off + 16])
+        state_to_log2(next_state, buf[off + 16:off + 32])
+        buf[off + 32], buf[off + 33] = int(action), 1 if done else 0
+        buf[off + 36:off + 40].view(np.float32)[0] = reward
         N.check(N.lib().q2048_q_update(
-            _ptr(b.table), b.capacity_log2, io.ptr, io.ptr + 32, io.ptr + 36, io.ptr + 16, io.ptr + 33,
-            1, 4, float(b.lr), float(b.gamma), b.env_id0, b.flags, _ptr(b.stats_i), _ptr(b.status),
-            _stream(b.device)), "q_update")
+            _ptr(b.table), b.capacity_log2, io.ptr + off, io.ptr + off + 32, io.ptr + off + 36,
+            io.ptr + off + 16, io.ptr + off + 33, 1, 4, float(b.lr), float(b.gamma), b.env_id0, b.flags,
+            _ptr(b.stats_i), _ptr(b.status), _stream(b.device)), "q_update")
 
     def decay_exploration(self, current_epoch) -> None:
         self._b.decay_exploration(current_epoch)

@@ -451,12 +451,12 @@ __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux*
   store_board(boards, i, B, b, st);
 }
 
-// The 4x4 single-step kernel of the 4-call API, software-pipelined.  With one board per thread the
-// whole device loads, then computes (~520 VALU per board), then stores, in lockstep: at 1 Mi boards
-// the grid is exactly two such rounds and neither the memory system nor the VALUs are busy for
-// more than half of the time.  Here a thread walks `boards / (grid * 256)` boards and requests
-// board, aux and action of the next one before it computes the current one, so loads of one
-// iteration fly under the arithmetic of another.
+// The 4x4 single-step kernel of the 4-call API: no LDS staging, and a thread can walk several
+// boards, requesting board, aux and action of the next one before it computes the current one.
+// Measured (profiles/r02_env_step.jsonl): one board per thread is the fastest setting, 15.0 us per
+// 1 Mi boards = 4.9 TB/s of the 70 B/step, 100 us per 8 Mi boards = 5.8 TB/s (93 % of the
+// 6.29 TB/s copy ceiling); at 1 Mi boards the ~540 VALU instructions per board and the two-round
+// grid leave the memory system idle for about a quarter of the launch.
 template <int ENV>
 __global__ __launch_bounds__(kBlock) void k_env_step4_pipelined(
     uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, uint64_t seed,
@@ -1275,9 +1275,10 @@ static int env_step_impl(uint8_t* boards, q2048_aux* aux, const uint8_t* actions
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
   if (n == 4 && draw_pos == nullptr) {
-    // pipelined kernel: 4 boards per thread once the batch fills the device (4 blocks of 4 waves
-    // per CU keep 4 loads per SIMD lane-slot in flight); experiment bits 8..11 override the count
-    const int64_t per_thread = ((flags >> 8) & 15u) ? (int64_t)((flags >> 8) & 15u) : 4;
+    // Boards per thread: 1 measures fastest (15.0 us per 1 Mi boards against 15.4 / 16.3 / 19.6 for
+    // 2 / 4 / 8: at 8 waves per SIMD the hardware already overlaps one wave's loads with another's
+    // arithmetic, and a longer thread only delays its own stores); experiment bits 8..11 override
+    const int64_t per_thread = ((flags >> 8) & 15u) ? (int64_t)((flags >> 8) & 15u) : 1;
     int64_t blocks = (B + kBlock * per_thread - 1) / (kBlock * per_thread);
     if (blocks > 0x7fffffff) blocks = 0x7fffffff;
     if (flags & Q2048_FLAG_ENV_DQN)

@@ -51,7 +51,8 @@ class BatchedGame2048Env:
     step counter), never on B or on how a batch is sharded over GPUs."""
 
     def __init__(self, num_envs: int, board_size: int = 4, device="cuda", seed: int = 0,
-                 env_id0: int = 0, profile: str = "shaped", reset_shaping_state: bool = False):
+                 env_id0: int = 0, profile: str = "shaped", reset_shaping_state: bool = False,
+                 host_visible: bool = False):
         """profile  "shaped" = Game2048_env of QLearningBase (the hot path's env);
                     "nopenalty" = the DQN path's Game2048_env,
                     Deep_QLearning/environment/Game2048_nopenalty_env.py: reward =
@@ -60,7 +61,10 @@ class BatchedGame2048Env:
                     Q2048_FLAG_ENV_DQN).
         reset_shaping_state  opt-in fix of a reference bug (Game2048_env.py:187-191 keeps
                     previous_max and the consecutive-action streak across reset()): resets also
-                    restore them to their constructor values.  Default: the reference's behaviour."""
+                    restore them to their constructor values.  Default: the reference's behaviour.
+        host_visible  keep boards / aux / outputs in pinned host memory that the kernels address
+                    directly (the one-env adapter: a step is one launch and one synchronisation,
+                    no copies).  For a handful of envs only: every access crosses PCIe."""
         self.device = _require_gpu(device)
         if board_size not in (4, 5):
             raise NotImplementedError("board_size must be 4 (the reference) or 5")
@@ -77,14 +81,23 @@ class BatchedGame2048Env:
         self.ctr = 0  # global step counter = counter word of the step draws
         self.action_space = _Discrete(4)                                 # Game2048_env.py:89
         B = self.num_envs
-        self.boards = torch.empty((B, self.cells), dtype=torch.uint8, device=self.device)
-        self.aux = torch.empty((B, 16), dtype=torch.uint8, device=self.device)
-        self._reward = torch.empty(B, dtype=torch.float32, device=self.device)
-        self._done = torch.empty(B, dtype=torch.uint8, device=self.device)
-        self._max = torch.empty(B, dtype=torch.uint8, device=self.device)
-        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.host_visible = bool(host_visible)
+
+        def alloc(shape, dtype):
+            if self.host_visible:                       # pinned + mapped: same address on the device
+                return torch.zeros(shape, dtype=dtype).pin_memory()
+            return torch.zeros(shape, dtype=dtype, device=self.device)
+
+        self.boards = alloc((B, self.cells), torch.uint8)
+        self.aux = alloc((B, 16), torch.uint8)
+        self._reward = alloc(B, torch.float32)
+        self._done = alloc(B, torch.uint8)
+        self._max = alloc(B, torch.uint8)
+        self.status = alloc(1, torch.int32)
         N.check(N.lib().q2048_env_init(_ptr(self.boards), _ptr(self.aux), B, self.board_size,
                                        self.seed, self.env_id0, _stream(self.device)), "env_init")
+        if self.host_visible:
+            torch.cuda.current_stream(self.device).synchronize()
 
     # -- reference surface ---------------------------------------------------------------
     def reset(self, mask: torch.Tensor | None = None) -> torch.Tensor:
@@ -94,6 +107,8 @@ class BatchedGame2048Env:
         N.check(N.lib().q2048_env_reset_ex(_ptr(self.boards), _ptr(self.aux), _ptr(mask),
                                            self.num_envs, self.board_size, self.seed, self.env_id0,
                                            self.env_flags, _stream(self.device)), "env_reset")
+        if self.host_visible:
+            torch.cuda.current_stream(self.device).synchronize()
         return self.boards
 
     def step(self, actions: torch.Tensor):
@@ -105,6 +120,8 @@ class BatchedGame2048Env:
             self.env_id0, self.ctr & 0xFFFFFFFF, self.env_flags, None, _ptr(self._reward),
             _ptr(self._done), _ptr(self._max), _ptr(self.status), _stream(self.device)), "env_step")
         self.ctr += 1
+        if self.host_visible:                           # host tensors: the launch has to finish first
+            torch.cuda.current_stream(self.device).synchronize()
         max_tile = torch.bitwise_left_shift(torch.ones_like(self._max, dtype=torch.int32),
                                             self._max.to(torch.int32))
         return self.boards, self._reward, self._done.bool(), max_tile
@@ -164,6 +181,8 @@ class BatchedGame2048Env:
 
     def check_status(self) -> int:
         """Synchronising read of the device status word; raises on a rejected action."""
+        if self.host_visible:
+            torch.cuda.current_stream(self.device).synchronize()
         s = int(self.status.item())
         if s & N.STATUS_BAD_ACTION:
             self.status.zero_()
@@ -179,7 +198,7 @@ class BatchedGame2048Env:
             if t.numel() and (int(t.min()) < 0 or int(t.max()) > 255):
                 raise ValueError(f"{name} out of range")
             t = t.to(torch.uint8)
-        t = t.to(self.device).contiguous()
+        t = (t.cpu().pin_memory() if self.host_visible else t.to(self.device)).contiguous()
         if t.shape != (self.num_envs,):
             raise ValueError(f"{name} must have shape ({self.num_envs},), got {tuple(t.shape)}")
         return t
@@ -219,7 +238,7 @@ class _Game:
 
     @property
     def board(self) -> np.ndarray:
-        return boards_to_raw(self._env._b.boards.cpu().numpy())[0]
+        return boards_to_raw(self._env._b.boards.numpy())[0]        # pinned host memory, in sync
 
 
 _LOG2_OF = {0: 0, **{1 << k: k for k in range(1, 32)}}
@@ -241,62 +260,73 @@ def state_to_log2(state, out: np.ndarray) -> None:
 
 
 class _Staging:
-    """64 bytes on the device + their pinned host mirror: the one-env adapters move their few
-    bytes with one copy in, one copy out and one stream synchronisation per call."""
+    """A ring of pinned host memory that the kernels address directly (pinned host memory is mapped
+    into the device's address space at the same address): the one-env adapters write their inputs
+    with numpy, launch, and read the outputs after one stream synchronisation -- no copy calls.
+    `take(n)` hands out the next n bytes; a region is not handed out again before the stream has
+    been synchronised, so a kernel still in flight never sees its inputs overwritten."""
 
-    def __init__(self, device: torch.device):
+    def __init__(self, device: torch.device, nbytes: int = 1 << 14):
         self.device = device
-        self.dev = torch.zeros(64, dtype=torch.uint8, device=device)
-        self.host_in = torch.zeros(64, dtype=torch.uint8)                 # pageable: reusable at once
-        self.host_out = torch.zeros(64, dtype=torch.uint8).pin_memory()
-        self.np_in, self.np_out = self.host_in.numpy(), self.host_out.numpy()
-        self.ptr = self.dev.data_ptr()
+        self.host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        self.np = self.host.numpy()
+        self.ptr = self.host.data_ptr()
+        self.pos = 0
+        self.pending = []                       # results not yet read back (see agent._LazyRow)
 
-    def upload(self, nbytes: int) -> None:
-        self.dev[:nbytes].copy_(self.host_in[:nbytes])
-
-    def download(self, lo: int, hi: int) -> None:
-        self.host_out[lo:hi].copy_(self.dev[lo:hi], non_blocking=True)
+    def take(self, nbytes: int) -> int:
+        nbytes = (nbytes + 15) & ~15
+        if self.pos + nbytes > self.np.size:
+            self.sync()
+            self.pos = 0
+        off, self.pos = self.pos, self.pos + nbytes
+        return off
 
     def sync(self) -> None:
         torch.cuda.current_stream(self.device).synchronize()
+        pending, self.pending = self.pending, []
+        for ref in pending:
+            obj = ref()
+            if obj is not None:
+                obj._read()
 
 
 class Game2048_env:
     """One env with the reference's exact surface and Python types
-    (Game2048_env.py:78-205): reset() -> int64[4,4], step(a) -> (board, float, bool, int)."""
+    (Game2048_env.py:78-205): reset() -> int64[4,4], step(a) -> (board, float, bool, int).
+    Board, aux and the step's outputs live in pinned host memory (`host_visible`), so a step is
+    one kernel launch and one stream synchronisation."""
 
-    def __init__(self, device="cuda", seed: int = 0, env_id: int = 0):
-        self._b = BatchedGame2048Env(1, 4, device, seed, env_id)
+    def __init__(self, device="cuda", seed: int = 0, env_id: int = 0, profile: str = "shaped",
+                 reset_shaping_state: bool = False):
+        self._b = BatchedGame2048Env(1, 4, device, seed, env_id, profile=profile,
+                                     reset_shaping_state=reset_shaping_state, host_visible=True)
         self.action_space = self._b.action_space
         self.game = _Game(self)
-        self._io = _Staging(self._b.device)          # [0:16] board, [16:20] reward, [20] done, [21] max
-        self._acts = torch.arange(4, dtype=torch.uint8, device=self._b.device)
-
-    def _board_out(self) -> np.ndarray:
-        io, b = self._io, self._b
-        io.host_out[0:16].copy_(b.boards.view(-1), non_blocking=True)
-        io.sync()
-        return boards_to_raw(io.np_out[0:16])
+        b = self._b
+        self._acts = torch.arange(4, dtype=torch.uint8).pin_memory()
+        self._board_np = b.boards.numpy().reshape(16)
+        self._reward_np, self._done_np, self._max_np = b._reward.numpy(), b._done.numpy(), b._max.numpy()
+        self._args = (b.boards.data_ptr(), b.aux.data_ptr())
+        self._outs = (b._reward.data_ptr(), b._done.data_ptr(), b._max.data_ptr(), b.status.data_ptr())
 
     def reset(self) -> np.ndarray:
-        self._b.reset()
-        return self._board_out()
+        self._b.reset()                                              # synchronises
+        return boards_to_raw(self._board_np)
 
     def step(self, action: int):
         action = int(action)
         if not 0 <= action <= 3:
             raise ValueError(f"action {action} outside 0..3")
-        io, b = self._io, self._b
-        N.check(N.lib().q2048_env_step(
-            _ptr(b.boards), _ptr(b.aux), self._acts.data_ptr() + action, 1, 4, b.seed, b.env_id0,
-            b.ctr & 0xFFFFFFFF, io.ptr + 16, io.ptr + 20, io.ptr + 21, _ptr(b.status),
-            _stream(b.device)), "env_step")
+        b = self._b
+        N.check(N.lib().q2048_env_step_ex(
+            self._args[0], self._args[1], self._acts.data_ptr() + action, 1, 4, b.seed, b.env_id0,
+            b.ctr & 0xFFFFFFFF, b.env_flags, None, self._outs[0], self._outs[1], self._outs[2],
+            self._outs[3], _stream(b.device)), "env_step")
         b.ctr += 1
-        io.download(16, 22)
-        board = self._board_out()                                    # + the synchronisation
-        out = io.np_out
-        return board, float(out[16:20].view(np.float32)[0]), bool(out[20]), 1 << int(out[21])
+        torch.cuda.current_stream(b.device).synchronize()
+        return (boards_to_raw(self._board_np), float(self._reward_np[0]), bool(self._done_np[0]),
+                1 << int(self._max_np[0]))
 
     @property
     def score(self) -> int:

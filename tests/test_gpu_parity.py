@@ -649,29 +649,54 @@ def test_sharding_invariance(pkg):
     assert np.allclose(mf, full_f, rtol=1e-9)
 
 
-def test_reference_surface_adapters(pkg):
-    """The reference loop body (Agent/main.py:80-109) runs unchanged on the adapters."""
-    env = pkg.Game2048_env(device=DEV, seed=3)
+def test_reference_surface_adapters(pkg, O):
+    """The reference loop body (Agent/main.py:80-109) runs unchanged on the adapters, and what it
+    computes is the reference's run: every board, action, reward and done flag, every Q row the
+    loop reads at :96 (returned lazily, read back thousands of steps later) and the final dict
+    equal the oracle's B = 1 loop under the same draws."""
+    seed = 3
+    env = pkg.Game2048_env(device=DEV, seed=seed)
     num_episodes = 3
-    agent = pkg.QLearningAgent(num_episodes, action_space=env.action_space.n, device=DEV, seed=3)
+    agent = pkg.QLearningAgent(num_episodes, action_space=env.action_space.n, device=DEV, seed=seed)
+    envs = O.envs_init(1, 4, seed, 0)
+    oa = O.Agent(num_episodes, 4)                      # the reference's defaults (Agent/main.py:15)
+    t, rows, want_rows = 0, [], []
     for episode in range(num_episodes):
         state = env.reset()
         assert state.shape == (4, 4) and state.dtype == np.int64
+        assert pkg.raw_to_boards(state).reshape(-1).tolist() == envs["board"][0, :16].tolist()
         state = tuple(map(tuple, state))
         done, total_reward, n = False, 0, 0
         while not done and n < 3000:
             action = agent.choose_action(state)
             next_state, reward, done, info = env.step(action)
             next_state = tuple(map(tuple, next_state))
-            q_values = agent.q_table[state]
+            q_values = agent.q_table[state]            # :96 -- before the update of :99 is queued
+            want_rows.append(oa.q(envs["board"][0, :16]))
+            si, sf, oact, orew, odn = O.rollout(envs, oa, 1, seed, 0, t, record=True)
+            assert (action, bool(done)) == (int(oact[0, 0]), bool(odn[0, 0])), t
+            assert abs(reward - float(np.float32(orew[0, 0]))) <= float(ulp32(orew[0, 0])), t
+            if not done:                               # (on done the oracle has already reset)
+                assert pkg.raw_to_boards(np.array(next_state)).reshape(-1).tolist() == envs["board"][0, :16].tolist(), t
             agent.update_q_value(state, action, reward, next_state, done)
+            rows.append(q_values)                      # not looked at until the run is over
             state = next_state
             total_reward += reward
             n += 1
-        assert done and isinstance(reward, float) and isinstance(info, int)
-        assert q_values.shape == (4,) and info == np.max(env.game.board)
+            t += 1
+        assert done and isinstance(reward, float) and isinstance(info, int) and isinstance(action, int)
+        assert q_values.shape == (4,) and len(q_values) == 4 and info == np.max(env.game.board)
         agent.decay_exploration(episode)
-    assert agent.epsilon == 0.01 and len(agent.q_table) > 10
+        oa.decay_exploration(episode)
+    assert agent.epsilon == oa.epsilon == 0.01 and len(agent.q_table) == len(oa) > 10
+    assert t > 200 and len(rows) == t
+    got = np.stack([np.asarray(r) for r in rows])
+    assert got.dtype == np.float64 and np.allclose(got, np.stack(want_rows), rtol=1e-5, atol=1e-6)
+    keys, vals = oa.dump()
+    final = np.stack([np.asarray(agent.q_table[tuple(map(tuple, pkg.boards_to_raw(k)))]) for k in keys[:200]])
+    assert np.allclose(final, vals[:200], rtol=1e-5, atol=1e-6)
+    assert str(rows[0]).startswith("[") and float(rows[-1][0]) == got[-1, 0] and rows[5].tolist() == got[5].tolist()
+    assert env.score == int(envs["score"][0])
 
 
 # ---------------------------------------------------------------------------------------------

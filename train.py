@@ -39,6 +39,9 @@ def parse_args(argv=None):
     p.add_argument("--epsilon", type=float, default=0.95, help="initial exploration rate (README.md:68)")
     p.add_argument("--epsilon-min", type=float, default=0.01)
     p.add_argument("--num-envs", type=int, default=1, help="boards per GPU")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="GPUs of this node: with N > 1 and no process group in the environment the script "
+                        "starts its own N ranks (one per GPU); under torchrun it joins the given group")
     p.add_argument("--board-size", type=int, default=4)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--device", default="cuda")
@@ -54,6 +57,15 @@ def parse_args(argv=None):
     p.add_argument("--max-steps", type=int, default=0, help="stop after this many env steps per env (0 = off)")
     p.add_argument("--episode-log", default="", help="batched mode: also write one row per finished "
                    "episode with the reference's columns (Agent/main.py:71-76) + Env to this CSV")
+    p.add_argument("--reset-shaping-state", action="store_true",
+                   help="opt-in fix of a reference bug: Game2048_env.reset (Game2048_env.py:187-191) keeps "
+                        "previous_max and the consecutive-action streak, so an episode ended by the "
+                        ">100-repeats rule ends again on its first repeated action; with this flag a reset "
+                        "restores them.  Default: the reference's behaviour, bit for bit")
+    p.add_argument("--env-profile", choices=["shaped", "nopenalty"], default="shaped",
+                   help="shaped = QLearningBase's Game2048_env (the reference's tabular path); nopenalty = "
+                        "the DQN path's env (Deep_QLearning/environment/Game2048_nopenalty_env.py: reward = "
+                        "merge score or -10, done = game over)")
     p.add_argument("--summary", default="", help="after the run, write the per-episode log's summary row "
                    "(layout of the reference's plots/summary_statistics_cleaned.csv) to this CSV")
     return p.parse_args(argv)
@@ -67,7 +79,8 @@ def log_debug_info(file_path, episode, action, q_values, reward, total_reward, m
 
 def train_single(args, pkg):
     """Agent/main.py:65-115 with the adapters: the loop body below is the reference's."""
-    env = pkg.Game2048_env(device=args.device, seed=args.seed)                         # :66
+    env = pkg.Game2048_env(device=args.device, seed=args.seed, profile=args.env_profile,  # :66
+                           reset_shaping_state=args.reset_shaping_state)
     num_episodes = args.episodes                                                       # :67
     agent = pkg.QLearningAgent(num_episodes, action_space=env.action_space.n,          # :68
                                learning_rate=args.alpha, discount_factor=args.gamma,
@@ -118,7 +131,9 @@ def train_batched(args, pkg):
     rows_per_episode = 256 if args.board_size == 4 else 2048     # 5x5 games last several times longer
     cap = args.capacity_log2 or int(min(32, max(20, np.ceil(np.log2(2.0 * B * rows_per_episode *
                                                                    max(args.episodes, 1))))))
-    env = pkg.BatchedGame2048Env(B, args.board_size, dev, args.seed, shard.env_id0)
+    env = pkg.BatchedGame2048Env(B, args.board_size, dev, args.seed, shard.env_id0,
+                                 profile=args.env_profile, reset_shaping_state=args.reset_shaping_state)
+    reducer = pkg.StatsAllReduce(dev)                 # the only collective, on a stream of its own
     if args.agent == "row-tuple":
         agent = pkg.BatchedRowTupleAgent(args.episodes, 4, args.alpha, args.gamma, args.epsilon,
                                          args.epsilon_min, dev, args.seed, shard.env_id0)
@@ -159,9 +174,8 @@ def train_batched(args, pkg):
                     wr.writerow(pkg.EpisodeLog.csv_row(rec) + [int(rec["env_id"])])
         if launches % args.report_every and not args.max_steps:
             continue
-        si, sf = agent.stats_i.clone(), agent.stats_f.clone()
-        pkg.allreduce_stats(si, sf)                       # the only collective: a few hundred bytes
-        st = pkg.stats_dict(si.cpu().numpy(), sf.cpu().numpy())
+        reducer.start(agent.stats_i, agent.stats_f)       # a few hundred bytes, summed over the ranks
+        st = pkg.stats_dict(*reducer.wait())
         total_eps = st["episodes"]
         while epoch < total_eps // shard.total_envs and epoch < args.episodes:
             agent.decay_exploration(epoch)                # Agent/main.py:109, once per epoch
@@ -184,6 +198,15 @@ def train_batched(args, pkg):
 
 def main(argv=None):
     args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the parent of the job has made no GPU call: one fresh process per rank (launch.py)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            "q2048_launch", os.path.join(REPO, "2048_q-learning_amd", "launch.py"))
+        launcher = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(launcher)
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+        raise SystemExit(launcher.launch_ranks(cmd, args.gpus))
     pkg = importlib.import_module("2048_q-learning_amd")
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     single = args.num_envs == 1 and world == 1
