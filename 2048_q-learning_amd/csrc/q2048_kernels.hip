@@ -788,11 +788,12 @@ template <int N, int ENV>
 __global__ __launch_bounds__(kBlock) void k_det_phase1(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
     uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, uint32_t* env_out,
-    double* target_out, int drop_bit, int64_t* stats_i, double* stats_f, uint32_t* status) {
+    double* target_out, int drop_bit, u64* longs, int64_t* stats_i, double* stats_f, uint32_t* status) {
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
   stats_clear(bs);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) longs[0] = 0ull;        // this step's list of long groups starts empty
   auto b = load_board(boards, i, B, st);
   if (i < B) {
     const uint64_t id = env_id0 + (uint64_t)i;
@@ -1414,6 +1415,11 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
 
 // workspace of q2048_det_rollout: double-buffered (group, env) pairs, targets, the list of long
 // groups, rocPRIM's temporary storage; every part 256-byte aligned
+// rocPRIM would merge-sort anything up to 1 Mi items (ten small kernels, ~150 us for 1 Mi 64-bit
+// keys); the least-significant-digit radix passes over the cap_log2 + 3 populated bits are ~3x
+// faster, so the merge path is limited to batches that fit a couple of blocks
+using DetSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                 rocprim::default_config, 8192>;
 struct DetLayout { size_t group[2], env[2], target, longs, sort, sort_bytes, total; };
 static int det_layout(int64_t B, int cap_log2, DetLayout& L) {
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1423,7 +1429,7 @@ static int det_layout(int64_t B, int cap_log2, DetLayout& L) {
   L.target = at; at += up((size_t)B * 8);
   L.longs = at; at += up(((size_t)B / (kDetSerial + 1) + 2) * 8);
   L.sort_bytes = 0;
-  if (rocprim::radix_sort_pairs<rocprim::default_config, u64*, u64*, uint32_t*, uint32_t*>(
+  if (rocprim::radix_sort_pairs<DetSortConfig, u64*, u64*, uint32_t*, uint32_t*>(
           nullptr, L.sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)B, 0u,
           (unsigned)(cap_log2 + 3), (hipStream_t)0) != hipSuccess)
     return Q2048_ERR_LAUNCH;
@@ -1465,11 +1471,10 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   const int drop_bit = cap_log2 + 2;
   for (int64_t t = 0; t < steps; ++t) {
     Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
-                     ctr0 + (uint32_t)t, flags, group[0], env[0], target, drop_bit, stats_i, stats_f,
-                     status);
-    if (hipMemsetAsync(longs, 0, 8, s) != hipSuccess) return Q2048_ERR_LAUNCH;
+                     ctr0 + (uint32_t)t, flags, group[0], env[0], target, drop_bit, longs, stats_i,
+                     stats_f, status);
     size_t sort_bytes = L.sort_bytes;
-    if (rocprim::radix_sort_pairs(ws + L.sort, sort_bytes, group[0], group[1], env[0], env[1], (size_t)B,
+    if (rocprim::radix_sort_pairs<DetSortConfig>(ws + L.sort, sort_bytes, group[0], group[1], env[0], env[1], (size_t)B,
                                   0u, (unsigned)(drop_bit + 1), s) != hipSuccess)
       return Q2048_ERR_LAUNCH;
     hipLaunchKernelGGL(k_det_apply, dim3(grid_for(B)), dim3(kBlock), 0, s, table, group[1], env[1], target,

@@ -659,6 +659,11 @@ def test_reference_surface_adapters(pkg, O):
     num_episodes = 3
     agent = pkg.QLearningAgent(num_episodes, action_space=env.action_space.n, device=DEV, seed=seed)
     envs = O.envs_init(1, 4, seed, 0)
+    # the loop resets the env before its first episode too (Agent/main.py:81): the constructor's
+    # game is never played; every later reset is the one the oracle's rollout makes on `done`
+    first = np.asarray(O.draws(seed, 0, 1, O.STREAM_RESET), dtype=np.uint32)
+    O.lib().orc_env_reset(envs.ctypes.data, O._u32(first))
+    envs["episode"][0] = 1
     oa = O.Agent(num_episodes, 4)                      # the reference's defaults (Agent/main.py:15)
     t, rows, want_rows = 0, [], []
     for episode in range(num_episodes):

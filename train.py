@@ -20,6 +20,7 @@ from __future__ import annotations
 import argparse
 import csv
 import importlib
+import importlib.util
 import os
 import sys
 import time
@@ -200,7 +201,6 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the parent of the job has made no GPU call: one fresh process per rank (launch.py)
-        import importlib.util
         spec = importlib.util.spec_from_file_location(
             "q2048_launch", os.path.join(REPO, "2048_q-learning_amd", "launch.py"))
         launcher = importlib.util.module_from_spec(spec)
