@@ -680,6 +680,8 @@ def test_reference_surface_adapters(pkg, O):
             want_rows.append(oa.q(envs["board"][0, :16]))
             si, sf, oact, orew, odn = O.rollout(envs, oa, 1, seed, 0, t, record=True)
             assert (action, bool(done)) == (int(oact[0, 0]), bool(odn[0, 0])), t
+            if done:                                   # env.score of the finished episode (:104)
+                assert env.score == int(si[O.ST_SCORE]) > 0
             assert abs(reward - float(np.float32(orew[0, 0]))) <= float(ulp32(orew[0, 0])), t
             if not done:                               # (on done the oracle has already reset)
                 assert pkg.raw_to_boards(np.array(next_state)).reshape(-1).tolist() == envs["board"][0, :16].tolist(), t
@@ -701,7 +703,6 @@ def test_reference_surface_adapters(pkg, O):
     final = np.stack([np.asarray(agent.q_table[tuple(map(tuple, pkg.boards_to_raw(k)))]) for k in keys[:200]])
     assert np.allclose(final, vals[:200], rtol=1e-5, atol=1e-6)
     assert str(rows[0]).startswith("[") and float(rows[-1][0]) == got[-1, 0] and rows[5].tolist() == got[5].tolist()
-    assert env.score == int(envs["score"][0])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1429,3 +1430,34 @@ def test_5x5_contended_creation_never_times_out(pkg, O):
     keys, _ = agent.export_rows()
     assert len(np.unique(keys, axis=0)) == len(keys)                              # no duplicate rows
     assert pkg._native.claim_timeouts() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-rank rehearsal on the one leased GPU
+# ---------------------------------------------------------------------------------------------
+def test_bench_self_launched_two_ranks_share_one_gpu():
+    """`python bench.py --gpus 2` with no process group in the environment: the script starts its
+    own two ranks (Q2048_DIST_BACKEND=gloo lets both sit on the one GPU of this box), each owns
+    half of the global env ids and its own table replica, and rank 0 prints ONE line whose
+    statistics are the all-reduced whole-job numbers.  (RCCL itself needs two GPUs: never run here.)"""
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    B, K = 1 << 16, 24
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["Q2048_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", str(K),
+                        "--warmup", "8", "--boards-per-gpu", str(B), "--cap-log2", "24", "--prep-steps", "256",
+                        "--repeats", "3", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == K and rec["warmup"] == 8
+    assert rec["config"]["total_boards"] == 2 * B and rec["config"]["boards_per_gpu"] == B
+    assert rec["stats"]["episodes"] > 0 and rec["stats"]["drops"] == 0 and rec["stats"]["status"] == 0
+    assert rec["cpu_baseline"] is None and "companions" not in rec
+    assert len(rec["region_ms"]) == 3 and rec["value"] > 0
+    assert abs(rec["value"] - 2 * B * K / (rec["ms_per_step"] * K / 1e3)) < 1e-6 * rec["value"]

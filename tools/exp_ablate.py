@@ -14,6 +14,10 @@ def run(name, bits, B=1 << 20, S=16, steps=128, warm=64, eps=0.95, cap_log2=32, 
         left = n
         while left > 0:
             k = min(S, left); agent.fused_rollout(env, k); left -= k
+    keep, agent.epsilon = agent.epsilon, 1.0       # input synthesis as in bench.py: random play, no learner
+    for _ in range(4):
+        agent.fused_rollout(env, 256, play_only=True)
+    agent.epsilon = keep
     agent.experiment_bits = bits if warm_bits is None else warm_bits
     go(warm); agent.stats(reset=True); torch.cuda.synchronize()
     agent.experiment_bits = bits
@@ -34,4 +38,5 @@ if __name__ == "__main__":
     for S in (1, 4, 64, 256):
         run(f"store_plain S={S}", 0, S=S, steps=256 if S >= 64 else 128)
     run("cas S=64", 1 << 8, S=64)
+    run("store_plain, immediate same-state writes", 1 << 14, S=64, steps=256)
     run("store_plain B=4M", 0, B=4 << 20, steps=64, cap_log2=32)
