@@ -282,6 +282,15 @@ def run_rank(args):
     # every step may create a row: load <= 0.5 at the end of the run, and beyond that half of the
     # device's free memory (a table that spans the memory system: DESIGN.md 4 "table placement")
     cap_log2 = args.cap_log2 or pkg.auto_capacity_log2(B * max(learn_steps, 1), dev, max_log2=32)
+    if args.agent == "hash" and args.cap_log2:
+        # a table given by hand must still end the run below load ~0.6 (0.75 new rows per board-step
+        # at the most), or every region is slower than the one before it: fewer regions, then
+        budget = int(0.6 * (1 << cap_log2) / (0.75 * B))
+        while args.repeats > 1 and args.warmup + args.repeats * args.steps > budget:
+            args.repeats -= 1
+        if args.warmup + args.repeats * args.steps > budget:
+            raise SystemExit(f"--cap-log2 {cap_log2} cannot hold {args.warmup} + {args.steps} steps of "
+                             f"{B} boards below load 0.6")
     algo_bytes = ALGO_BYTES_FUSED_4X4 if args.board_size == 4 else ALGO_BYTES_FUSED_5X5
     if args.agent == "row-tuple":
         algo_bytes = ALGO_BYTES_ROW_TUPLE
@@ -314,7 +323,9 @@ def run_rank(args):
         roofline["physical_minimum"] = {
             "bytes_per_env_step": phys, "achieved": per_launch_phys / s["avg_launch_s"] / 1e9,
             "frac": per_launch_phys / s["avg_launch_s"] / 1e9 / HBM_PEAK_GBS,
-            "note": "useful bytes only (no line granularity); the memory system moves whole 64-B lines"}
+            "note": "useful bytes only; what the memory system moves for them is `traffic`: every L2 "
+                    "miss is a 128-B read request whatever the load's width or cache policy, write-backs "
+                    "are 32 B, atomics 64 B (profiles/r02_requests/)"}
         cfg = {"boards": shard.num_envs, "steps_per_launch": S, "cap_log2": cap_log2,
                "board_size": args.board_size, "eps": args.eps, "strict_td": bool(args.strict_td)}
         per_step, source, other = committed_pmc_traffic(cfg)

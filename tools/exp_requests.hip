@@ -6,6 +6,10 @@
 //
 //   hipcc -O3 --offload-arch=gfx950 -o tools/variants/exp_requests tools/exp_requests.hip
 //   tools/variants/exp_requests [cap_log2=28] [lanes_log2=20] [steps=64] [alloc_log2=cap_log2]
+//                               [only: run the combinations whose name contains this] [alloc mode:
+//                               0 hipMalloc, 1 fine-grained, 3 uncached (hipExtMallocWithFlags)]
+// Round 2 added: whole 64- / 128-byte lines written by one lane, a 1-bit-per-slot occupancy
+// bitmap (load + atomic OR as the claim), every cache-policy flavour of the probe load.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
