@@ -25,7 +25,7 @@ using namespace q2048;
 
 constexpr int kBlock = 256;
 constexpr int kMaxProbe = 256;   // probe limit: beyond it a lookup reads "absent", an update drops
-constexpr int kMaxCas = 4096;    // TD compare-and-swap retries before the additive fallback
+constexpr int kMaxCas = 16;      // TD compare-and-swap attempts before the update is simply stored
 
 static_assert(sizeof(q2048_aux) == 16 && sizeof(q2048_slot) == 32, "ABI layout");
 static_assert(sizeof(q2048_episode) == 48, "ABI layout");
@@ -306,13 +306,14 @@ __device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, co
 //   STORE (default)  one 4-byte store of the new value: when several lanes update the same
 //          (s, a) at the same time the last writer wins (never a torn value).
 //   CAS (Q2048_FLAG_TD_CAS)  compare-and-swap loop: a failed swap returns the live value and
-//          the update is recomputed from it, so concurrent updates of one (s, a) serialise.
+//          the update is recomputed from it, so concurrent updates of one (s, a) serialise -- for
+//          up to kMaxCas attempts, after which the update is stored as in STORE mode.
 //   The other modes are measurement variants selected by experiment bits 8..11 of flags.
 enum : uint32_t { kTdStorePlain = 0, kTdCas = 1, kTdStoreSc1 = 2, kTdStoreNt = 3, kTdNone = 4,
                   kTdAdd = 6 };
 __device__ __forceinline__ float td_update(q2048_slot* slot, int a, float guess, float reward,
                                            float max_next, bool done, double lr, double gamma,
-                                           uint32_t& retries, uint32_t mode) {
+                                           uint32_t& retries, uint32_t mode, int max_cas = kMaxCas) {
   unsigned int* addr = reinterpret_cast<unsigned int*>(&slot->q[a]);
   unsigned int expect = f32_bits(guess);
   float nq = td_value(guess, reward, max_next, done, lr, gamma);
@@ -324,14 +325,18 @@ __device__ __forceinline__ float td_update(q2048_slot* slot, int a, float guess,
   if (mode == kTdStoreNt) { __builtin_nontemporal_store(f32_bits(nq), addr); return nq; }
   if (mode == kTdNone) return nq;
   if (mode == kTdAdd) { atomicAdd(&slot->q[a], nq - guess); return nq; }
-  for (int it = 0; it < kMaxCas; ++it) {
+  for (int it = 0; it < max_cas; ++it) {
     const unsigned int prev = atomicCAS(addr, expect, f32_bits(nq));
     if (prev == expect) return nq;
     ++retries;
     expect = prev;
     nq = td_value(bits_f32(expect), reward, max_next, done, lr, gamma);
   }
-  atomicAdd(&slot->q[a], nq - bits_f32(expect));  // extreme contention: keep the sample
+  // 16 lost races in a row: the entry is being rewritten every few hundred nanoseconds.  Spinning on
+  // costs far more than the sample is worth -- unbounded, a few such entries (the opening states
+  // at low epsilon) stretched every wave's step 4x (181 -> 71 us per 1 Mi boards at eps = 0.01,
+  // profiles/r02_strict_td_retries.jsonl) -- so the update is written as the default mode writes it
+  *addr = f32_bits(nq);
   return nq;
 }
 // Deferred TD writes: while a lane stays in one state (invalid moves: the board did not change)
@@ -675,6 +680,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
     uint32_t retries = 0, pend = 0;
     double reward_sum = 0.0;
     const bool may_defer = td_mode == kTdStorePlain && !((flags >> 14) & 1u);  // bit 14: experiment, off
+    const int max_cas = ((flags >> 16) & 0xffu) ? (int)((flags >> 16) & 0xffu) : kMaxCas;  // experiment
 
     for (int t = 0; t < steps; ++t) {
       const Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
           pend |= 1u << act;
         } else {
           nq = td_update(&table[slot_s], act, row_get(q, act), o.reward, max_next, o.done != 0, lr,
-                         gamma, retries, td_mode);
+                         gamma, retries, td_mode, max_cas);
           pend &= ~(1u << act);
           if (pend) flush_pending(&table[slot_s], q, pend);
         }

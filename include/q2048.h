@@ -60,8 +60,10 @@ extern "C" {
 #define Q2048_FLAG_INDEPENDENT 1u /* every env owns private Q rows (key salted by its global id) */
 #define Q2048_FLAG_SINGLE_ENV 2u  /* q_lookup: every board belongs to env `env_id0` (not env_id0 + i) */
 #define Q2048_FLAG_TD_CAS 4u      /* TD update by a compare-and-swap loop: concurrent updates of one
-                                     (s, a) serialise instead of "last writer wins"; identical to
-                                     the default whenever no two lanes share (s, a) */
+                                     (s, a) serialise instead of "last writer wins" (for up to 16
+                                     attempts per update; an entry contended beyond that takes the
+                                     update as a plain store); identical to the default whenever
+                                     no two lanes share (s, a) */
 
 #define Q2048_FLAG_ENV_DQN 8u      /* env step = the DQN path's env instead of Game2048_env.step:
                                      Deep_QLearning/environment/Game2048_nopenalty_env.py:106-138 --

@@ -759,6 +759,11 @@ def test_5x5_fused_rollout_matches_oracle_independent_lanes(pkg, O):
         assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), i
         worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
     print(f"[q] 5x5 fused: worst relative Q error {worst:.2e}")
+    # agent.q_table[state] (Agent/main.py:16,96) with a 5x5 state: rows of env id0 (lane 0)
+    k0, v0 = agents[0].dump()
+    for j in (0, len(k0) // 2, len(k0) - 1):
+        state = tuple(map(tuple, pkg.boards_to_raw(k0[j])))
+        assert len(state) == 5 and np.allclose(agent.q_table[state], v0[j], rtol=1e-5, atol=1e-6)
     st = agent.stats()
     assert st["steps"] == B * steps and st["episodes"] == tot_i[O.ST_EPISODES]
     assert st["valid_moves"] == tot_i[O.ST_VALID] and st["score_sum"] == tot_i[O.ST_SCORE]

@@ -110,3 +110,38 @@ def test_short_training_loops(ref, O, seed, env_id, eps):
     assert np.array_equal(d[:, 0], tr["dones"])
     assert np.array_equal(envs["board"][:, :16], tr["final_boards"]) and len(agent) == len(tr["q_keys"])
     assert np.array_equal(np.stack([agent.q(k) for k in tr["q_keys"]]), tr["q_vals"])
+
+
+# ---- the DQN path's env (Deep_QLearning/environment/Game2048_nopenalty_env.py), live ---------------
+@pytest.fixture(scope="module")
+def ref_dqn(ref):
+    gg = ref[0]
+    return gg, gg.import_reference_dqn_env()
+
+
+# boards weighted towards full ones: is_game_over's own moves only happen there
+dqn_boards = st.one_of(boards, st.lists(st.integers(1, 5), min_size=16, max_size=16),
+                       st.lists(st.integers(1, 3), min_size=16, max_size=16))
+
+
+@settings(**CFG)
+@given(board=dqn_boards, action=st.integers(0, 3), d0=u32, d1=u32, d2=u32, d3=u32, score0=st.integers(0, 5000))
+def test_dqn_env_step(ref_dqn, O, board, action, d0, d1, d2, d3, score0):
+    """One step of the reference's second env (calculate_reward2, done = game_over, the board that
+    is_game_over leaves in moved_board) == orc_env_step_dqn, both draw pairs routed as the build
+    assigns them."""
+    gg, dqn_mod = ref_dqn
+    feed = gg.Feed()
+    with gg.InjectedDqn(dqn_mod, feed):
+        feed.env_q = [0] * 4
+        e = dqn_mod.Game2048_env()
+        e.game.board = gg.raw(board).astype(int)
+        e.score = score0
+        feed.env_q, feed.over_q = [d0, d1], [d2, d3]
+        b, r, d, m = e.step(action)
+        want = (gg.lg(b).tolist(), float(r), bool(d), int(m), int(e.score))
+    o = O.Env(4)
+    o.set_board(board)
+    o.rec["score"][0] = score0
+    gb, gr, gd, gm, _ = o.step_dqn(action, d0, d1, d2, d3)
+    assert (gb.tolist(), gr, gd, (1 << gm) if gm else 0, int(o.rec["score"][0])) == want
