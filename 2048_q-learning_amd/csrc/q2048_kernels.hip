@@ -461,7 +461,9 @@ __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux*
 // Measured (profiles/r02_env_step.jsonl): one board per thread is the fastest setting, 15.0 us per
 // 1 Mi boards = 4.9 TB/s of the 70 B/step, 100 us per 8 Mi boards = 5.8 TB/s (93 % of the
 // 6.29 TB/s copy ceiling); at 1 Mi boards the ~540 VALU instructions per board and the two-round
-// grid leave the memory system idle for about a quarter of the launch.
+// grid leave the memory system idle for about a quarter of the launch.  Starting every other
+// block 1-8 Ki cycles late (a stagger, so that one half computes while the other loads) measured
+// 15.1 us at best, worse beyond 2 Ki cycles (profiles/r02_env_step_stagger.jsonl): not kept.
 template <int ENV>
 __global__ __launch_bounds__(kBlock) void k_env_step4_pipelined(
     uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, uint64_t seed,
