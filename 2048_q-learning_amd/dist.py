@@ -52,9 +52,14 @@ def env_from_torchrun() -> tuple[int, int, int]:
 
 
 def init_process_group(backend: str | None = None) -> tuple[int, int, int]:
-    """Joins the job's process group (no-op for a single process).  `nccl` is RCCL on ROCm."""
+    """Joins the job's process group.  A process that was not started as a rank of a job (no
+    WORLD_SIZE in its environment) stays alone; a launched one joins its group even when the job
+    has a single rank, so that `torch.distributed.run --nproc-per-node 1` drives exactly the code
+    a multi-GPU job runs (RCCL initialisation, the collectives, the side stream) -- the one part
+    of the N > 1 path a one-GPU box can exercise.  `nccl` is RCCL on ROCm."""
     rank, local_rank, world = env_from_torchrun()
-    if world > 1 and not dist.is_initialized():
+    launched = "WORLD_SIZE" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -63,8 +68,9 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, int]:
                 "nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            kw["device_id"] = torch.device("cuda", local_rank)
+            dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+            torch.cuda.set_device(dev)
+            kw["device_id"] = dev
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
@@ -74,7 +80,7 @@ def allreduce_stats(stats_i: torch.Tensor, stats_f: torch.Tensor, group=None):
     sums, histogram bins).  Tensors stay where they are (HBM for nccl, host for gloo)."""
     if stats_i.numel() != N.NSTAT_I or stats_f.numel() != N.NSTAT_F:
         raise ValueError("unexpected statistics vector length")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():        # a 1-rank group still runs the collective
         dist.all_reduce(stats_i, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(stats_f, op=dist.ReduceOp.SUM, group=group)
     return stats_i, stats_f
@@ -98,7 +104,7 @@ class StatsAllReduce:
     def start(self, stats_i: torch.Tensor, stats_f: torch.Tensor) -> None:
         if stats_i.numel() != N.NSTAT_I or stats_f.numel() != N.NSTAT_F:
             raise ValueError("unexpected statistics vector length")
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        multi = dist.is_available() and dist.is_initialized()    # a 1-rank group still runs the collective
         if self.side is None:
             self._si, self._sf = stats_i.clone(), stats_f.clone()
             if multi:
@@ -131,7 +137,7 @@ class StatsAllReduce:
 
 def max_over_ranks(value: float, device=None, group=None) -> float:
     """MAX all-reduce of one float (bench timing: the slowest rank defines the step time)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -139,7 +145,7 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
 
 
 def barrier(group=None) -> None:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier(group=group)
 
 

@@ -402,7 +402,7 @@ def run_rank(args):
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -1468,3 +1468,30 @@ def test_bench_self_launched_two_ranks_share_one_gpu():
     assert rec["cpu_baseline"] is None and "companions" not in rec
     assert len(rec["region_ms"]) == 3 and rec["value"] > 0
     assert abs(rec["value"] - 2 * B * K / (rec["ms_per_step"] * K / 1e3)) < 1e-6 * rec["value"]
+
+
+def test_bench_under_torchrun_one_rank_drives_rccl():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: a launched rank joins
+    its process group even when it is alone, so this is the N > 1 code path end to end on RCCL --
+    `init_process_group("nccl", device_id=...)`, the statistics all-reduce on the side stream, the MAX
+    all-reduce of the region times, the barriers -- with the one rank a one-GPU box has."""
+    import socket
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "Q2048_DIST_BACKEND")}
+    B, K = 1 << 16, 16
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", str(K), "--warmup", "4",
+                        "--boards-per-gpu", str(B), "--cap-log2", "24", "--prep-steps", "128", "--repeats", "3",
+                        "--cpu-seconds", "0", "--no-companions"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.lstrip().startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["config"]["total_boards"] == B and rec["stats"]["episodes"] > 0
+    assert "RCCL" in rec["config"]["parallelism"] and rec["stats"]["status"] == 0
