@@ -328,12 +328,13 @@ Q_HD StepOut env_step(BoardT& b, Aux& a, int action, uint32_t x_pos, uint32_t x_
   return o;
 }
 
-// Env profiles (template parameter ENV of the kernels = Q2048_FLAG_ENV_DQN / _RESET_SHAPING >> 3):
+// Env profiles (template parameter ENV of the kernels, from Q2048_FLAG_ENV_DQN / _RESET_SHAPING / _PLAY_ONLY):
 //   kEnvDqn           step of the DQN path's env, Deep_QLearning/environment/
 //                     Game2048_nopenalty_env.py:106-138, instead of Game2048_env.step
 //   kEnvResetShaping  resets also restore previous_max and the consecutive-action state
 //                     (SURVEY 7.8 opt-in; Game2048_env.reset, :187-191, leaves them alone)
-constexpr int kEnvDqn = 1, kEnvResetShaping = 2;
+//   kEnvPlayOnly      (fused rollout only) no learner: the table is neither read nor written
+constexpr int kEnvDqn = 1, kEnvResetShaping = 2, kEnvPlayOnly = 4;
 
 // Game2048_nopenalty_env.step (:106-120) with the caller's `env.game.board = next_state`
 // (mainDQL_CNN_step2.py:237) folded in: on return b is moved_board.

@@ -667,9 +667,11 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
     const uint64_t id = env_id0 + (uint64_t)i;
     const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
     const uint32_t td_mode = td_mode_of(flags);
-    // Q2048_FLAG_PLAY_ONLY: the table is never touched (every row reads as zeros, nothing is
-    // created or written).  Experiment bits (not ABI): 12 no row creation, 13 no next-state probe
-    const bool play_only = (flags & Q2048_FLAG_PLAY_ONLY) != 0;
+    // Q2048_FLAG_PLAY_ONLY (ENV bit kEnvPlayOnly: its own instantiation, so profiles tell the
+    // learner-less launches from the learning ones): the table is never touched -- every row reads
+    // as zeros, nothing is created or written.  Experiment bits (not ABI): 12 no row creation,
+    // 13 no next-state probe
+    constexpr bool play_only = (ENV & kEnvPlayOnly) != 0;
     const bool x_noclaim = ((flags >> 12) & 1u) || play_only, x_noprobe = ((flags >> 13) & 1u) || play_only;
     Aux a = ld_aux(aux, i);
     auto key_s = state_key(b, salt, status);
@@ -1210,14 +1212,27 @@ inline int check_table(const void* table, int cap_log2) {
                          (hipStream_t)(stream), __VA_ARGS__);                                     \
     break;
 #define Q2048_LAUNCH_ENV(kernel, flags, n, B, stream, ...)                                        \
-  switch (env_bits(flags)) {                                                                      \
+  switch (env_bits(flags) & 3) {                                                                  \
     Q2048_LAUNCH_ENV_CASE(kernel, 0, n, B, stream, __VA_ARGS__)                                   \
     Q2048_LAUNCH_ENV_CASE(kernel, 1, n, B, stream, __VA_ARGS__)                                   \
     Q2048_LAUNCH_ENV_CASE(kernel, 2, n, B, stream, __VA_ARGS__)                                   \
     Q2048_LAUNCH_ENV_CASE(kernel, 3, n, B, stream, __VA_ARGS__)                                   \
   }
+// ... and with the play-only bit (the fused rollout)
+#define Q2048_LAUNCH_ENV8(kernel, flags, n, B, stream, ...)                                       \
+  switch (env_bits(flags)) {                                                                      \
+    Q2048_LAUNCH_ENV_CASE(kernel, 0, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 1, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 2, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 3, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 4, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 5, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 6, n, B, stream, __VA_ARGS__)                                   \
+    Q2048_LAUNCH_ENV_CASE(kernel, 7, n, B, stream, __VA_ARGS__)                                   \
+  }
 inline int env_bits(uint32_t flags) {
-  return ((flags & Q2048_FLAG_ENV_DQN) ? kEnvDqn : 0) | ((flags & Q2048_FLAG_RESET_SHAPING) ? kEnvResetShaping : 0);
+  return ((flags & Q2048_FLAG_ENV_DQN) ? kEnvDqn : 0) | ((flags & Q2048_FLAG_RESET_SHAPING) ? kEnvResetShaping : 0) |
+         ((flags & Q2048_FLAG_PLAY_ONLY) ? kEnvPlayOnly : 0);
 }
 }  // namespace
 
@@ -1415,7 +1430,7 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
   if (steps < 0 || steps > (1 << 30)) return Q2048_ERR_SIZE;
   if (!(eps >= 0.0 && eps <= 1.0) || !(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
   if (B == 0 || steps == 0) return Q2048_OK;
-  Q2048_LAUNCH_ENV(k_fused_rollout, flags, n, B, stream, boards, aux, table,
+  Q2048_LAUNCH_ENV8(k_fused_rollout, flags, n, B, stream, boards, aux, table,
                    (u64)((1ull << cap_log2) - 1ull), B, (int)steps, eps, lr, gamma, seed, env_id0, ctr0,
                    flags, stats_i, stats_f, status, log, log_capacity, reinterpret_cast<u64*>(log_count));
   return launch_status();

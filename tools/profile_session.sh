@@ -10,8 +10,10 @@ bad() { [ "$1" -eq 124 ] || [ "$1" -eq 137 ]; }
 
 echo "== bench default"
 timeout -k 10 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; rc=$?; cat "$OUT/bench.json"; bad $rc && exit 1
-echo "== rocprofv3 --kernel-trace --stats of the same command"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py > "$OUT/prof_bench.json" 2> "$OUT/prof.err"; rc=$?; echo "rc=$rc"; bad $rc && exit 1
+echo "== rocprofv3 --kernel-trace --stats of the same command (without the companion runs, so that every"
+echo "   k_fused_rollout<4, 0> dispatch is a 64-step learning launch of the measured configuration: 1 warm-up +"
+echo "   5 x 4 timed; the input synthesis runs as k_fused_rollout<4, 4>, the learner-less instantiation)"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py --no-companions --cpu-seconds 0 > "$OUT/prof_bench.json" 2> "$OUT/prof.err"; rc=$?; echo "rc=$rc"; bad $rc && exit 1
 find "$OUT/prof" -name "*kernel_stats.csv" | head -n 1 | while read -r f; do cut -d, -f1-4,8 "$f" | head -n 8; done
 echo "== driver-style short run"
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_k20.json" 2> "$OUT/bench_k20.err"; rc=$?; cut -c1-400 "$OUT/bench_k20.json"; bad $rc && exit 1
