@@ -7,6 +7,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 root = sys.argv[1]
@@ -30,6 +31,9 @@ for d in sorted(glob.glob(os.path.join(root, "pass*"))):
     print("==", os.path.basename(d))
     for (k, c), per in sorted(acc.items()):
         if "k_fused_rollout" not in k and "k_table" not in k:
+            continue
+        m = re.search(r"k_fused_rollout<\d, (\d)>", k)
+        if m and int(m.group(1)) & 4:      # the learner-less instantiation (input synthesis): not the measured kernel
             continue
         vals = [per[i] for i in sorted(per)]
         tail = vals[-timed:] if (timed and "k_fused_rollout" in k) else vals
