@@ -20,7 +20,7 @@ DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.in
 OK = 0
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
 FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
-FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY = 8, 16, 32
+FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY, FLAG_NO_LEARN = 8, 16, 32, 64
 ABI_VERSION = 2
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
 ST_HIST0, NSTAT_I = 8, 32

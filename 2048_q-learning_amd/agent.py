@@ -263,13 +263,14 @@ class BatchedQLearningAgent:
 
     # -- throughput entry point ----------------------------------------------------------
     def fused_rollout(self, env: BatchedGame2048Env, steps: int, episode_log: "EpisodeLog | None" = None,
-                      play_only: bool = False) -> None:
+                      play_only: bool = False, learn: bool = True) -> None:
         """`steps` iterations of choose -> step -> update -> accumulate -> reset-on-done
         (Agent/main.py:91-101, :81) for every env in ONE launch.  Statistics accumulate in
         `stats_i` / `stats_f` on the device (read them with `stats()`); with `episode_log` every
         finished episode also leaves one record (the reference's CSV row, :103-105).  The env's
         profile flags travel with the call.  `play_only`: no learner -- the table is neither read
-        nor written (every row reads as zeros); with epsilon = 1 that is uniformly random play."""
+        nor written (every row reads as zeros); with epsilon = 1 that is uniformly random play.
+        `learn=False`: evaluation -- actions come from the stored rows, nothing is created or written."""
         if env.device != self.device:
             raise ValueError("env and agent live on different devices")
         if (env.seed, env.env_id0) != (self.seed, self.env_id0):
@@ -283,7 +284,8 @@ class BatchedQLearningAgent:
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
             self.board_size, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
             self.env_id0, self.ctr & 0xFFFFFFFF,
-            self.flags | self.experiment_bits | env.env_flags | (N.FLAG_PLAY_ONLY if play_only else 0),
+            self.flags | self.experiment_bits | env.env_flags | (N.FLAG_PLAY_ONLY if play_only else 0) |
+            (0 if learn else N.FLAG_NO_LEARN),
             _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status),
             _ptr(log.records) if log is not None else None, log.capacity if log is not None else 0,
             _ptr(log.count) if log is not None else None, _stream(self.device)), "fused_rollout")

@@ -666,13 +666,16 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
   if (i < B) {
     const uint64_t id = env_id0 + (uint64_t)i;
     const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
-    const uint32_t td_mode = td_mode_of(flags);
+    const uint32_t td_mode = (flags & Q2048_FLAG_NO_LEARN) ? (uint32_t)kTdNone : td_mode_of(flags);
     // Q2048_FLAG_PLAY_ONLY (ENV bit kEnvPlayOnly: its own instantiation, so profiles tell the
     // learner-less launches from the learning ones): the table is never touched -- every row reads
     // as zeros, nothing is created or written.  Experiment bits (not ABI): 12 no row creation,
     // 13 no next-state probe
     constexpr bool play_only = (ENV & kEnvPlayOnly) != 0;
-    const bool x_noclaim = ((flags >> 12) & 1u) || play_only, x_noprobe = ((flags >> 13) & 1u) || play_only;
+    // Q2048_FLAG_NO_LEARN: evaluation of a trained table -- rows are read (epsilon-greedy over the
+    // stored values), nothing is created or written
+    const bool no_learn = (flags & Q2048_FLAG_NO_LEARN) != 0;
+    const bool x_noclaim = ((flags >> 12) & 1u) || play_only || no_learn, x_noprobe = ((flags >> 13) & 1u) || play_only;
     Aux a = ld_aux(aux, i);
     auto key_s = state_key(b, salt, status);
     Row q{0.f, 0.f, 0.f, 0.f};
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
       n_valid += wave_count(o.valid != 0);
       n_explore += wave_count(explored);
       n_insert += wave_count(ins_s) + wave_count(ins_n);
-      n_drop += wave_count(!updated && !play_only);
+      n_drop += wave_count(!updated && !play_only && !no_learn);
       n_done += wave_count(o.done != 0);
       reward_sum += (double)o.reward;
     }

@@ -84,6 +84,11 @@ extern "C" {
                                      uniformly random play (input synthesis for benchmarks, the
                                      arithmetic floor of the kernel) */
 
+#define Q2048_FLAG_NO_LEARN 64u    /* fused rollout that evaluates a trained table: rows are looked up
+                                     (epsilon-greedy over the stored values), nothing is created or
+                                     written.  What the `evaluate.py` the reference's README lists
+                                     (README.md:52, no such file in the repository) has to do */
+
 /* per-env state, Game2048_env.__init__ (Game2048_env.py:81-95) + episode bookkeeping */
 typedef struct q2048_aux {
   int32_t score;       /* env.score (:84); zeroed by reset (:190) */
@@ -225,7 +230,7 @@ int q2048_q_lookup(const q2048_slot *table, int cap_log2, const uint8_t *boards,
  * aux and the Q row of the current state stay in registers between steps.  Step t uses the
  * draws of counter ctr0 + t.  Bit-identical to calling q_choose / env_step / q_update /
  * env_reset(done) `steps` times whenever no two lanes share a state.
- * flags: Q2048_FLAG_INDEPENDENT, _TD_CAS, _ENV_DQN, _RESET_SHAPING, _PLAY_ONLY. */
+ * flags: Q2048_FLAG_INDEPENDENT, _TD_CAS, _ENV_DQN, _RESET_SHAPING, _PLAY_ONLY, _NO_LEARN. */
 int q2048_fused_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2,
                         int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
                         uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,

@@ -1499,3 +1499,58 @@ def test_bench_under_torchrun_one_rank_drives_rccl():
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.lstrip().startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["config"]["total_boards"] == B and rec["stats"]["episodes"] > 0
     assert "RCCL" in rec["config"]["parallelism"] and rec["stats"]["status"] == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluation of a trained table (the reference README's evaluate.py / models/)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [4, 5])
+def test_no_learn_rollout_reads_but_never_writes(pkg, O, n):
+    """Q2048_FLAG_NO_LEARN: after some training, play on with the stored values only.  The table is
+    bit-identical afterwards (no row created, no value written) and every trajectory equals the
+    oracle agent's with its learning rate set to 0 (same lookups, same argmax, frozen values)."""
+    B, train_steps, eval_steps, seed, id0, eps = 128, 300, 250, 9, 4242, 0.15
+    envs = O.envs_init(B, n, seed, id0)
+    agents = [O.Agent(100, 4, 0.1, 0.95, eps, n=n) for _ in range(B)]
+    for i in range(B):
+        O.rollout(envs[i:i + 1], agents[i], train_steps, seed, id0 + i, 0)
+        agents[i]._view().lr = 0.0
+        O.rollout(envs[i:i + 1], agents[i], eval_steps, seed, id0 + i, train_steps)
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.95, exploration_rate=eps,
+                                      capacity_log2=18, seed=seed, env_id0=id0, device=DEV,
+                                      independent=True, board_size=n)
+    agent.fused_rollout(env, train_steps)
+    before = agent.table.clone()
+    rows = agent.table_size()
+    agent.stats(reset=True)
+    agent.fused_rollout(env, 100, learn=False)
+    agent.fused_rollout(env, eval_steps - 100, learn=False)
+    assert torch.equal(agent.table, before) and agent.table_size() == rows       # nothing written
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :n * n])
+    assert_aux(env.aux_fields(), envs, "no-learn")
+    st = agent.stats()
+    assert st["steps"] == B * eval_steps and st["inserts"] == 0 and st["drops"] == 0
+    assert st["episodes"] > 0 and agent.check_status() == 0
+
+
+def test_train_save_then_evaluate_scripts(tmp_path):
+    """`train.py --save` writes the learner, `evaluate.py` plays it greedily without learning and
+    `train.py --resume` continues from it (the README's train / evaluate / models layout)."""
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    model = str(tmp_path / "models" / "q.pt")
+    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))  # noqa: E731
+    p = run(os.path.join(REPO, "train.py"), "--num-envs", "4096", "--episodes", "3", "--steps-per-launch", "32",
+            "--report-every", "4", "--capacity-log2", "24", "--save", model, "--log", str(tmp_path / "t.csv"))
+    assert p.returncode == 0 and os.path.exists(model), p.stderr[-2000:]
+    p = run(os.path.join(REPO, "evaluate.py"), "--model", model, "--num-envs", "2048", "--episodes", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["games"] >= 2 * 2048 and rec["rows"] > 10000 and rec["epsilon"] == 0.0 and rec["best_tile"] >= 64
+    p = run(os.path.join(REPO, "train.py"), "--num-envs", "4096", "--episodes", "1", "--steps-per-launch", "32",
+            "--report-every", "4", "--capacity-log2", "24", "--resume", model, "--log", str(tmp_path / "t2.csv"))
+    assert p.returncode == 0, p.stderr[-2000:]

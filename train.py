@@ -67,6 +67,10 @@ def parse_args(argv=None):
                    help="shaped = QLearningBase's Game2048_env (the reference's tabular path); nopenalty = "
                         "the DQN path's env (Deep_QLearning/environment/Game2048_nopenalty_env.py: reward = "
                         "merge score or -10, done = game over)")
+    p.add_argument("--save", default="", help="write the trained learner (Q-table rows, epsilon schedule, counters) "
+                   "to this file when training ends -- the models/ directory of the reference's README; "
+                   "evaluate.py and --resume read it")
+    p.add_argument("--resume", default="", help="continue from a file written by --save (same agent arguments)")
     p.add_argument("--summary", default="", help="after the run, write the per-episode log's summary row "
                    "(layout of the reference's plots/summary_statistics_cleaned.csv) to this CSV")
     return p.parse_args(argv)
@@ -88,6 +92,8 @@ def train_single(args, pkg):
                                exploration_rate=args.epsilon, exploration_min=args.epsilon_min,
                                capacity_log2=args.capacity_log2 or 22, device=args.device,
                                seed=args.seed)
+    if args.resume:
+        agent._b.load_state_dict(_load(args.resume, 0))
     log_file = args.log                                                                # :71
     with open(log_file, mode="w", newline="") as file:                                 # :74-76
         csv.writer(file).writerow(["Episode", "Action", "Q-Values", "Reward", "Total-Reward", "Max Value"])
@@ -144,6 +150,11 @@ def train_batched(args, pkg):
                                           strict_td=args.strict_td, board_size=args.board_size)
     if args.deterministic and args.agent != "hash":
         raise SystemExit("--deterministic applies to the hash-table agent")
+    if (args.save or args.resume) and args.agent != "hash":
+        raise SystemExit("--save / --resume apply to the hash-table agent")
+    if args.resume:
+        agent.load_state_dict(_load(args.resume, rank))
+        env.ctr = agent.ctr                       # fresh boards, the learner's draw counter
     if rank == 0:
         with open(args.log, mode="w", newline="") as fh:
             csv.writer(fh).writerow(["Epoch", "Episodes", "Env-Steps", "Epsilon", "Mean-Return",
@@ -197,6 +208,22 @@ def train_batched(args, pkg):
     return agent
 
 
+def _load(path, rank):
+    import torch
+
+    return torch.load(path if rank == 0 and not os.path.exists(f"{path}.rank0") else f"{path}.rank{rank}",
+                      map_location="cpu", weights_only=False)
+
+
+def _save(agent, path, world, rank):
+    """One file per rank (every rank trains its own replica): PATH for a single process, PATH.rankR in a job."""
+    import torch
+
+    batched = agent._b if hasattr(agent, "_b") else agent
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(batched.state_dict(compact=True), path if world == 1 else f"{path}.rank{rank}")
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -213,6 +240,8 @@ def main(argv=None):
     if args.summary and not single and not args.episode_log:
         raise SystemExit("--summary needs a per-episode log: --episode-log in batched mode")
     agent = train_single(args, pkg) if single else train_batched(args, pkg)
+    if args.save:
+        _save(agent, args.save, world, rank)
     if args.summary:                               # one row per log, like the reference's aggregate
         episodes_csv = args.log if single else (args.episode_log if world == 1 else f"{args.episode_log}.rank{rank}")
         out = args.summary if world == 1 else f"{args.summary}.rank{rank}"
