@@ -733,7 +733,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
           const u64 at = atomicAdd(log_count, 1ull);
           if ((int64_t)at < log_cap) {
             Row ql = q;
-            if (updated) row_set(ql, act, nq);   // the logged row is the live one (:96), post-update
+            if (updated && !no_learn) row_set(ql, act, nq);   // the logged row is the live one (:96), post-update
             q2048_episode rec;
             rec.env_id = id; rec.episode = a.episode; rec.action = (uint8_t)act;
             rec.max_log2 = o.max_log2; rec.steps_lo = (uint16_t)(ctr0 + (uint32_t)t);
@@ -750,8 +750,8 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
         slot_s = play_only ? kNoSlot : probe_find(table, mask, key_s, q, made);
         ins_n = ins_n || made;
       } else if (same) {            // invalid move: same state, its row just changed (:100)
-        if (updated) row_set(q, act, nq);
-        else slot_s = kNoSlot;      // dropped: do not retry the claim with a stale hint
+        if (updated && !no_learn) row_set(q, act, nq);   // (evaluation: the stored row stays as it is)
+        else if (!updated) slot_s = kNoSlot;             // dropped: do not retry the claim with a stale hint
       } else {
         key_s = key_n; slot_s = slot_n; q = qn;                                        // :100
         if (!x_noclaim) {

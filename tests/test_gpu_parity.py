@@ -1528,7 +1528,11 @@ def test_no_learn_rollout_reads_but_never_writes(pkg, O, n):
     agent.fused_rollout(env, eval_steps - 100, learn=False)
     assert torch.equal(agent.table, before) and agent.table_size() == rows       # nothing written
     assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :n * n])
-    assert_aux(env.aux_fields(), envs, "no-learn")
+    f = env.aux_fields()
+    for k, v in oracle_aux(envs).items():
+        assert np.array_equal(f[k].astype(np.int64), np.asarray(v, dtype=np.int64)), k
+    # the running return is a float32 sum on the device (550 terms here): 1e-4, not the 1e-5 of a Q value
+    assert np.allclose(f["ep_return"], envs["episode_return"], rtol=1e-4, atol=1e-3)
     st = agent.stats()
     assert st["steps"] == B * eval_steps and st["inserts"] == 0 and st["drops"] == 0
     assert st["episodes"] > 0 and agent.check_status() == 0
