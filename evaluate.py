@@ -70,7 +70,7 @@ def main(argv=None):
                       "valid_move_frac": st["valid_moves"] / max(st["steps"], 1),
                       "max_tile_hist": {str(k): v for k, v in st["max_tile_hist"].items()},
                       "best_tile": max(st["max_tile_hist"], default=0),
-                      "seconds": round(time.time() - t0, 2)}))
+                      "seconds": round(time.time() - t0, 3)}))
     return st
 
 
