@@ -1444,8 +1444,14 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
 // rocPRIM would merge-sort anything up to 1 Mi items (ten small kernels, ~150 us for 1 Mi 64-bit
 // keys); the least-significant-digit radix passes over the cap_log2 + 3 populated bits are ~3x
 // faster, so the merge path is limited to batches that fit a couple of blocks
-using DetSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                 rocprim::default_config, 8192>;
+// and of the onesweep settings tried (tools/exp_sort.hip, profiles/r02_sort_configs.jsonl: 2^20 pairs
+// over 33 bits) blocks of 1024 x 4 items, 8 bits per pass, wave-match ranking are the fastest:
+// 133 us against 156 for the library's default and 194 for its merge sort
+using DetSortConfig = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<1024, 4>, 8,
+                                        rocprim::block_radix_rank_algorithm::match>,
+    8192>;
 struct DetLayout { size_t group[2], env[2], target, longs, sort, sort_bytes, total; };
 static int det_layout(int64_t B, int cap_log2, DetLayout& L) {
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };

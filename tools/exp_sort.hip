@@ -31,6 +31,25 @@ static void run(const char* name, u64* kin, u64* kout, uint32_t* vin, uint32_t* 
   CK(hipFree(tmp));
 }
 
+template <class Config>
+static void run32(const char* name, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned bits) {
+  size_t bytes = 0;
+  CK((rocprim::radix_sort_pairs<Config>(nullptr, bytes, kin, kout, vin, vout, n, 0u, bits, (hipStream_t)0)));
+  void* tmp;
+  CK(hipMalloc(&tmp, bytes + 256));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) CK((rocprim::radix_sort_pairs<Config>(tmp, bytes, kin, kout, vin, vout, n, 0u, bits, (hipStream_t)0)));
+  CK(hipEventRecord(e0, 0));
+  const int reps = 20;
+  for (int r = 0; r < reps; ++r) CK((rocprim::radix_sort_pairs<Config>(tmp, bytes, kin, kout, vin, vout, n, 0u, bits, (hipStream_t)0)));
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  std::printf("{\"config\": \"%s\", \"n\": %zu, \"bits\": %u, \"us_per_sort\": %.1f}\n", name, n, bits, ms * 1e3 / reps);
+  std::fflush(stdout);
+  CK(hipFree(tmp));
+}
+
 template <unsigned BS, unsigned IPT, unsigned RB, rocprim::block_radix_rank_algorithm A>
 using Cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                        rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<BS, IPT>, RB, A>, 8192>;
@@ -56,5 +75,16 @@ int main(int argc, char** argv) {
   run<Cfg<256, 12, 7, R::match>>("256x12 7b match", kin, kout, vin, vout, n, bits);
   run<Cfg<256, 12, 6, R::match>>("256x12 6b match", kin, kout, vin, vout, n, bits);
   run<Cfg<256, 8, 8, R::match>>("256x8 8b match", kin, kout, vin, vout, n, bits);
+  // 32-bit keys (tables of up to 2^29 slots: slot << 2 | action, + the drop bit, fit)
+  if (bits <= 32) {
+    uint32_t* k32 = reinterpret_cast<uint32_t*>(kin);
+    uint32_t* k32o = reinterpret_cast<uint32_t*>(kout);
+    std::vector<uint32_t> kk(n);
+    for (size_t i = 0; i < n; ++i) kk[i] = (uint32_t)k[i];
+    CK(hipMemcpy(k32, kk.data(), n * 4, hipMemcpyHostToDevice));
+    run32<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 8192>>("u32 keys, default onesweep", k32, k32o, vin, vout, n, bits);
+    run32<rocprim::default_config>("u32 keys, default (merge sort)", k32, k32o, vin, vout, n, bits);
+    run32<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<1024, 4>, 8, R::match>, 8192>>("u32 keys, 1024x4 8b match", k32, k32o, vin, vout, n, bits);
+  }
   return 0;
 }
