@@ -100,6 +100,9 @@ class StatsAllReduce:
         self.side = torch.cuda.Stream(self.device) if on_gpu else None
         self._si = self._sf = None
         self._done = None
+        # the reduced vectors land in pinned host memory on the side stream: wait() is one event wait
+        self._host_i = torch.zeros(N.NSTAT_I, dtype=torch.int64).pin_memory() if on_gpu else None
+        self._host_f = torch.zeros(N.NSTAT_F, dtype=torch.float64).pin_memory() if on_gpu else None
 
     def start(self, stats_i: torch.Tensor, stats_f: torch.Tensor) -> None:
         if stats_i.numel() != N.NSTAT_I or stats_f.numel() != N.NSTAT_F:
@@ -118,6 +121,8 @@ class StatsAllReduce:
             if multi:
                 dist.all_reduce(self._si, op=dist.ReduceOp.SUM, group=self.group)
                 dist.all_reduce(self._sf, op=dist.ReduceOp.SUM, group=self.group)
+            self._host_i.copy_(self._si, non_blocking=True)
+            self._host_f.copy_(self._sf, non_blocking=True)
             self._si.record_stream(self.side)
             self._sf.record_stream(self.side)
             self._done = torch.cuda.Event()
@@ -130,7 +135,9 @@ class StatsAllReduce:
         if self._done is not None:
             self._done.synchronize()
             self._done = None
-        si, sf = self._si.cpu().numpy(), self._sf.cpu().numpy()
+            si, sf = self._host_i.numpy().copy(), self._host_f.numpy().copy()
+        else:
+            si, sf = self._si.cpu().numpy(), self._sf.cpu().numpy()
         self._si = self._sf = None
         return si, sf
 
