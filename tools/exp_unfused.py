@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Measurement tool: the reference's loop body through the batched 4-call API (choose_action ->
+step -> update_q_value -> reset(done): four launches per env-step, driven from Python) next to the
+fused rollout, same job."""
+import importlib
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("2048_q-learning_amd")
+dev = torch.device("cuda:0")
+for B in (1 << 20, 1 << 16):
+    env = pkg.BatchedGame2048Env(B, seed=0, device=dev)
+    agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99, exploration_rate=0.95,
+                                      capacity_log2=32 if B == 1 << 20 else 28, seed=0, device=dev, placement="plain")
+    agent.fused_rollout(env, 256, play_only=True)
+
+    def loop(steps):
+        for _ in range(steps):
+            s = env.boards.clone()
+            a = agent.choose_action(s)
+            s2, r, d, _ = env.step(a)
+            agent.update_q_value(s, a, r, s2, d)
+            env.reset(d)
+
+    loop(8)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    steps = 64
+    e0.record(); loop(steps); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(json.dumps({"api": "4-call (choose, step, update, reset) + 1 board copy per step", "B": B, "steps": steps,
+                      "us_per_step": round(ms * 1e3 / steps, 1), "env_steps_per_s": B * steps / ms * 1e3}), flush=True)
+    agent.ctr = env.ctr
+    e0.record(); agent.fused_rollout(env, steps); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(json.dumps({"api": "fused_rollout", "B": B, "steps": steps, "us_per_step": round(ms * 1e3 / steps, 1),
+                      "env_steps_per_s": B * steps / ms * 1e3}), flush=True)
+    del agent, env
+    torch.cuda.empty_cache()
