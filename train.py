@@ -128,9 +128,11 @@ def train_batched(args, pkg):
     import torch
 
     rank, local_rank, world = pkg.dist.init_process_group()
-    dev = torch.device(args.device if ":" in args.device or world == 1 else f"cuda:{local_rank}")
-    if dev.type == "cuda" and dev.index is None:
-        dev = torch.device("cuda", local_rank)
+    if ":" in args.device:
+        dev = torch.device(args.device)
+    else:       # one rank = one GPU of the node (ranks share GPUs only in rehearsals on a smaller box)
+        dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
     shard = pkg.weak_shard(args.num_envs, world, rank)
     B = shard.num_envs
     # ~220 steps per episode, most of them reach a new state: size for the whole run (load <= 0.5),
