@@ -1558,3 +1558,26 @@ def test_train_save_then_evaluate_scripts(tmp_path):
     p = run(os.path.join(REPO, "train.py"), "--num-envs", "4096", "--episodes", "1", "--steps-per-launch", "32",
             "--report-every", "4", "--capacity-log2", "24", "--resume", model, "--log", str(tmp_path / "t2.csv"))
     assert p.returncode == 0, p.stderr[-2000:]
+
+
+def test_train_self_launched_two_ranks_share_one_gpu(tmp_path):
+    """`python train.py --gpus 2`: two self-launched ranks (gloo, both on this box's one GPU), each
+    with its shard of the env ids and its own table; rank 0's CSV holds the all-reduced numbers."""
+    import csv
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["Q2048_DIST_BACKEND"] = "gloo"
+    log = tmp_path / "train.csv"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "train.py"), "--gpus", "2", "--num-envs", "4096",
+                        "--episodes", "2", "--steps-per-launch", "32", "--report-every", "4",
+                        "--capacity-log2", "24", "--log", str(log)], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    rows = list(csv.DictReader(open(log)))
+    assert rows and int(rows[-1]["Epoch"]) == 2
+    assert int(rows[-1]["Episodes"]) >= 2 * 8192                      # both shards' episodes
+    assert int(rows[-1]["Env-Steps"]) % (8192 * 32) == 0 and int(rows[-1]["Drops"]) == 0
