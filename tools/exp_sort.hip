@@ -75,6 +75,10 @@ int main(int argc, char** argv) {
   run<Cfg<256, 12, 7, R::match>>("256x12 7b match", kin, kout, vin, vout, n, bits);
   run<Cfg<256, 12, 6, R::match>>("256x12 6b match", kin, kout, vin, vout, n, bits);
   run<Cfg<256, 8, 8, R::match>>("256x8 8b match", kin, kout, vin, vout, n, bits);
+  run<Cfg<1024, 6, 8, R::match>>("1024x6 8b match", kin, kout, vin, vout, n, bits);
+  run<Cfg<1024, 8, 8, R::match>>("1024x8 8b match", kin, kout, vin, vout, n, bits);
+  run<Cfg<1024, 2, 8, R::match>>("1024x2 8b match", kin, kout, vin, vout, n, bits);
+  run<Cfg<1024, 4, 7, R::match>>("1024x4 7b match", kin, kout, vin, vout, n, bits);
   // 32-bit keys (tables of up to 2^29 slots: slot << 2 | action, + the drop bit, fit)
   if (bits <= 32) {
     uint32_t* k32 = reinterpret_cast<uint32_t*>(kin);
