@@ -263,7 +263,6 @@ def summarise(m, shard, steps, algo_bytes):
 
 
 def run_rank(args):
-    import numpy as np  # noqa: F401  (the package needs it; fail early)
     import torch
 
     pkg = importlib.import_module("2048_q-learning_amd")

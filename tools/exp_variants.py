@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput sweep of the fused kernel (experiments; prints one line per configuration)."""
-import importlib, json, os, sys, time
+import importlib, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
