@@ -314,8 +314,8 @@ class BatchedQLearningAgent:
         N.check(L.q2048_det_rollout(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, B, self.board_size,
             int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed, self.env_id0,
-            self.ctr & 0xFFFFFFFF, self.flags | env.env_flags, _ptr(self.stats_i), _ptr(self.stats_f),
-            _ptr(self.status), base, need, _stream(self.device)), "det_rollout")
+            self.ctr & 0xFFFFFFFF, self.flags | env.env_flags | self.experiment_bits, _ptr(self.stats_i),
+            _ptr(self.stats_f), _ptr(self.status), base, need, _stream(self.device)), "det_rollout")
         env.ctr += int(steps)
         self.ctr += int(steps)
 

@@ -854,67 +854,96 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
   stats_flush(bs, stats_i, stats_f);
 }
 
-// Phase 2 on the sorted updates: group[j] = (slot << 2) | action ascending, env order inside a
-// group (the sort is stable and phase 1 wrote envs in order).  Agent/main.py:43 is the affine map
-// q -> (1 - lr) q + lr * target; a group applies its maps in env order, in double precision, and
-// rounds to float32 once -- for one update that is exactly td_value().  The first lane of a group
-// walks up to kDetSerial updates itself; longer groups (the handful of states many envs share,
-// e.g. right after a reset) go on a list for k_det_apply_long, one wave per group.
-constexpr int kDetSerial = 32;
+// Phase 2.  The updates arrive sorted -- stably, so env order survives -- by the LOW `sort_bits`
+// bits of group = (slot << 2) | action only: slots are hash values, so 16 bits (two radix passes
+// instead of five) already cut 2^20 updates into ~65 000 runs of ~16, and inside a run the
+// handful of distinct groups are told apart by comparing the full words.  Agent/main.py:43 is the
+// affine map q -> (1 - lr) q + lr * target; a group applies its maps in env order, in double
+// precision, and rounds to float32 once -- for one update that is exactly td_value().
+//   k_det_apply       the first lane of a run of up to kDetRun updates walks it: for every group
+//                     in the run (in order of first appearance) it folds the group's updates in
+//                     env order and writes the cell.  Longer runs -- the states many envs share,
+//                     e.g. right after a reset -- go on a list;
+//   k_det_apply_long  one wave per listed run: group after group, every lane composes the maps of
+//                     its contiguous share that belong to the group, the shares are composed in
+//                     order with a shuffle tree, lane 0 applies the result.
+// Which path a group takes and the shape of the tree depend on the sorted data only: the result
+// does not depend on scheduling.  kDetDone marks an update as applied (the sorted array is scratch).
+constexpr int kDetRun = 64;
+constexpr u64 kDetDone = 1ull << 63;
 __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u64* group,
                                                       const uint32_t* env, const double* target,
-                                                      int64_t B, double lr, int drop_bit, u64* longs) {
+                                                      int64_t B, double lr, int drop_bit, u64 run_mask,
+                                                      u64* longs) {
   const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (j >= B) return;
-  const u64 g = group[j];
-  if ((g >> drop_bit) != 0ull || (j > 0 && group[j - 1] == g)) return;   // dropped, or not a head
+  const u64 g0 = group[j];
+  if (j > 0 && ((group[j - 1] ^ g0) & run_mask) == 0ull) return;         // not the head of a run
   int len = 1;
-  while (len <= kDetSerial && j + len < B && group[j + len] == g) ++len;
-  if (len > kDetSerial) {            // at most B / 33 such groups: the list cannot overflow
+  while (len <= kDetRun && j + len < B && ((group[j + len] ^ g0) & run_mask) == 0ull) ++len;
+  if (len > kDetRun) {               // at most B / 65 such runs: the list cannot overflow
     longs[1ull + atomicAdd(&longs[0], 1ull)] = (u64)j;
     return;
   }
-  float* cell = &table[g >> 2].q[g & 3ull];
-  double q = (double)*cell;
-  for (int k = 0; k < len; ++k) q = q + lr * (target[env[j + k]] - q);  // Agent/main.py:43
-  *cell = (float)q;
+  u64 done = 0ull;                   // bit k: update j + k has been applied
+  for (int i = 0; i < len; ++i) {
+    if ((done >> i) & 1ull) continue;
+    const u64 g = group[j + i];
+    if ((g >> drop_bit) != 0ull) continue;                                 // dropped in phase 1
+    float* cell = &table[g >> 2].q[g & 3ull];
+    double q = (double)*cell;
+    for (int k = i; k < len; ++k)
+      if (group[j + k] == g) {
+        q = q + lr * (target[env[j + k]] - q);                             // Agent/main.py:43
+        done |= 1ull << k;
+      }
+    *cell = (float)q;
+  }
 }
 
-// One wave per long group: every lane composes the affine maps of a contiguous share of the
-// group, (a, b) meaning q -> a q + b, the shares are composed in order with a shuffle tree, and
-// lane 0 applies the result.  The tree depends only on the group's length: deterministic.
-__global__ __launch_bounds__(kBlock) void k_det_apply_long(q2048_slot* table, const u64* group,
+__global__ __launch_bounds__(kBlock) void k_det_apply_long(q2048_slot* table, u64* group,
                                                            const uint32_t* env, const double* target,
-                                                           int64_t B, double lr, const u64* longs) {
+                                                           int64_t B, double lr, int drop_bit,
+                                                           u64 run_mask, const u64* longs) {
   const u64 n_long = longs[0];
   const uint32_t lane = threadIdx.x & 63u;
   const u64 waves = (u64)gridDim.x * (kBlock / 64);
   for (u64 w = (u64)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n_long; w += waves) {
     const int64_t start = (int64_t)longs[1ull + w];
-    const u64 g = group[start];
-    int64_t len = 0;                                     // wave-uniform search for the group's end
+    const u64 g0 = group[start];
+    int64_t len = 0;                                     // wave-uniform search for the run's end
     for (;;) {
       const int64_t pos = start + len + (int64_t)lane;
-      const u64 same = __ballot(pos < B && group[pos] == g);
+      const u64 same = __ballot(pos < B && ((group[pos] ^ g0) & run_mask) == 0ull);
       if (same != ~0ull) { len += (int64_t)(__ffsll((long long)~same) - 1); break; }
       len += 64;
     }
     const int64_t share = (len + 63) / 64;
     const int64_t lo = start + (int64_t)lane * share;
     const int64_t hi = lo + share < start + len ? lo + share : start + len;
-    double a = 1.0, b = 0.0;                             // identity for lanes beyond the group
-    for (int64_t k = lo; k < hi; ++k) {
-      a = a * (1.0 - lr);
-      b = b * (1.0 - lr) + lr * target[env[k]];
-    }
+    int64_t cur = lo;                                    // first update of this share not yet applied
+    for (;;) {
+      while (cur < hi && (group[cur] >> drop_bit) != 0ull) ++cur;          // applied (bit 63) or dropped
+      const u64 have = __ballot(cur < hi);
+      if (have == 0ull) break;
+      const int first = __ffsll((long long)have) - 1;   // shares are in order: the run's first open update
+      const u64 g = __shfl(cur < hi ? group[cur] : 0ull, first);
+      double a = 1.0, b = 0.0;                           // identity for lanes without an update of g
+      for (int64_t k = cur; k < hi; ++k)
+        if (group[k] == g) {
+          a = a * (1.0 - lr);
+          b = b * (1.0 - lr) + lr * target[env[k]];
+          group[k] = g | kDetDone;
+        }
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {                   // (lane + d) after lane: a_hi (a q + b) + b_hi
-      const double a_hi = __shfl_down(a, d), b_hi = __shfl_down(b, d);
-      if ((lane & (2u * d - 1u)) == 0u) { b = a_hi * b + b_hi; a = a_hi * a; }
-    }
-    if (lane == 0u) {
-      float* cell = &table[g >> 2].q[g & 3ull];
-      *cell = (float)(a * (double)*cell + b);
+      for (int d = 1; d < 64; d <<= 1) {                 // (lane + d) after lane: a_hi (a q + b) + b_hi
+        const double a_hi = __shfl_down(a, d), b_hi = __shfl_down(b, d);
+        if ((lane & (2u * d - 1u)) == 0u) { b = a_hi * b + b_hi; a = a_hi * a; }
+      }
+      if (lane == 0u) {
+        float* cell = &table[g >> 2].q[g & 3ull];
+        *cell = (float)(a * (double)*cell + b);
+      }
     }
   }
 }
@@ -1459,7 +1488,7 @@ static int det_layout(int64_t B, int cap_log2, DetLayout& L) {
   for (int k = 0; k < 2; ++k) { L.group[k] = at; at += up((size_t)B * 8); }
   for (int k = 0; k < 2; ++k) { L.env[k] = at; at += up((size_t)B * 4); }
   L.target = at; at += up((size_t)B * 8);
-  L.longs = at; at += up(((size_t)B / (kDetSerial + 1) + 2) * 8);
+  L.longs = at; at += up(((size_t)B / (kDetRun + 1) + 2) * 8);
   L.sort_bytes = 0;
   if (rocprim::radix_sort_pairs<DetSortConfig, u64*, u64*, uint32_t*, uint32_t*>(
           nullptr, L.sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)B, 0u,
@@ -1501,18 +1530,24 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   const hipStream_t s = (hipStream_t)stream;
   const u64 mask = (1ull << cap_log2) - 1ull;
   const int drop_bit = cap_log2 + 2;
+  // sort width: the low 16 bits tell runs apart (comment at k_det_apply); experiment bits 8..13 of
+  // flags override it (the tests sort by 3 and by 8 bits to force crowded runs, and by all bits)
+  const int full_bits = drop_bit + 1;
+  int sort_bits = (int)((flags >> 8) & 63u) ? (int)((flags >> 8) & 63u) : 16;
+  if (sort_bits > full_bits) sort_bits = full_bits;
+  const u64 run_mask = (1ull << sort_bits) - 1ull;
   for (int64_t t = 0; t < steps; ++t) {
     Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
                      ctr0 + (uint32_t)t, flags, group[0], env[0], target, drop_bit, longs, stats_i,
                      stats_f, status);
     size_t sort_bytes = L.sort_bytes;
     if (rocprim::radix_sort_pairs<DetSortConfig>(ws + L.sort, sort_bytes, group[0], group[1], env[0], env[1], (size_t)B,
-                                  0u, (unsigned)(drop_bit + 1), s) != hipSuccess)
+                                  0u, (unsigned)sort_bits, s) != hipSuccess)
       return Q2048_ERR_LAUNCH;
     hipLaunchKernelGGL(k_det_apply, dim3(grid_for(B)), dim3(kBlock), 0, s, table, group[1], env[1], target,
-                       B, lr, drop_bit, longs);
+                       B, lr, drop_bit, run_mask, longs);
     hipLaunchKernelGGL(k_det_apply_long, dim3(256), dim3(kBlock), 0, s, table, group[1], env[1], target, B,
-                       lr, longs);
+                       lr, drop_bit, run_mask, longs);
     if (int e = launch_status()) return e;
   }
   return Q2048_OK;

@@ -1290,11 +1290,17 @@ def test_c_host_program_drives_the_abi(pkg, tmp_path):
     assert np.isclose(got["return_sum"], st["return_sum"], rtol=1e-9)
 
 
-@pytest.mark.parametrize("n,B,steps", [(4, 3000, 80), (5, 1500, 60), (4, 60000, 24)])
-def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, n, B, steps):
+@pytest.mark.parametrize("n,B,steps,sort_bits", [(4, 3000, 80, 0), (5, 1500, 60, 0), (4, 60000, 24, 0),
+                                                  (4, 3000, 80, 3), (5, 1500, 60, 8), (4, 60000, 24, 63),
+                                                  (4, 60000, 24, 10)])
+def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, n, B, steps, sort_bits):
     """Shared table, lanes meeting on common states, epsilon < 1 (actions depend on Q): the
     deterministic mode equals the oracle's two-phase semantic -- boards bit-exact, the WHOLE
-    Q-table within tolerance -- and two runs give bit-identical tables.
+    Q-table within tolerance -- and two runs give bit-identical tables.  `sort_bits` (experiment
+    bits of the flags; 0 = the default 16) sets how many bits of (row, action) the updates are
+    sorted by: 3 and 8 make every run of the sorted array a crowd of different groups (each told
+    apart by the full word), 63 sorts by everything (a run is a group), 10 mixes long runs with
+    crowded ones.
     (Not run at 1,048,576 boards: from reset, thousands of lanes sit on symmetric opening states whose
     two mirror actions hold values that are equal in the device's float32 table and 2e-14 apart in
     the oracle's float64 one -- 2.867381811141947 vs ...966 measured -- so the two argmaxes pick
@@ -1308,6 +1314,7 @@ def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, n, B, steps
         env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
         agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
                                           capacity_log2=22, seed=seed, env_id0=id0, device=DEV, board_size=n)
+        agent.experiment_bits = sort_bits << 8
         agent.deterministic_rollout(env, steps // 2)          # two calls: the counter carries over
         agent.deterministic_rollout(env, steps - steps // 2)
         return env, agent
