@@ -860,10 +860,11 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
 // handful of distinct groups are told apart by comparing the full words.  Agent/main.py:43 is the
 // affine map q -> (1 - lr) q + lr * target; a group applies its maps in env order, in double
 // precision, and rounds to float32 once -- for one update that is exactly td_value().
-//   k_det_apply       the first lane of a run of up to kDetRun updates walks it: for every group
-//                     in the run (in order of first appearance) it folds the group's updates in
-//                     env order and writes the cell.  Longer runs -- the states many envs share,
-//                     e.g. right after a reset -- go on a list;
+//   k_det_apply       runs of up to kDetRun updates: the first update of every group in the run
+//                     folds the group's updates in env order and writes the cell (one lane per
+//                     update scans its run; ~700 000 independent read-modify-writes in flight).
+//                     Longer runs -- the states many envs share, e.g. right after a reset -- are
+//                     listed by their first update;
 //   k_det_apply_long  one wave per listed run: group after group, every lane composes the maps of
 //                     its contiguous share that belong to the group, the shares are composed in
 //                     order with a shuffle tree, lane 0 applies the result.
@@ -877,28 +878,27 @@ __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u
                                                       u64* longs) {
   const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (j >= B) return;
-  const u64 g0 = group[j];
-  if (j > 0 && ((group[j - 1] ^ g0) & run_mask) == 0ull) return;         // not the head of a run
-  int len = 1;
-  while (len <= kDetRun && j + len < B && ((group[j + len] ^ g0) & run_mask) == 0ull) ++len;
-  if (len > kDetRun) {               // at most B / 65 such runs: the list cannot overflow
-    longs[1ull + atomicAdd(&longs[0], 1ull)] = (u64)j;
+  const u64 g = group[j];
+  // every update looks at its own run (neighbours in the sorted array, cached): is an earlier
+  // update of the run in the same group (then that one folds this one in), how far does the run go
+  bool first = true;
+  int back = 0, fwd = 0;
+  while (back < kDetRun && j - back - 1 >= 0 && ((group[j - back - 1] ^ g) & run_mask) == 0ull) {
+    first = first && group[j - back - 1] != g;
+    ++back;
+  }
+  while (fwd < kDetRun && j + fwd + 1 < B && ((group[j + fwd + 1] ^ g) & run_mask) == 0ull) ++fwd;
+  if (back + fwd + 1 > kDetRun) {    // a long run (every update of it sees that): the wave kernel's
+    if (back == 0)                   // its head lists it; at most B / 65 such runs, no overflow
+      longs[1ull + atomicAdd(&longs[0], 1ull)] = (u64)j;
     return;
   }
-  u64 done = 0ull;                   // bit k: update j + k has been applied
-  for (int i = 0; i < len; ++i) {
-    if ((done >> i) & 1ull) continue;
-    const u64 g = group[j + i];
-    if ((g >> drop_bit) != 0ull) continue;                                 // dropped in phase 1
-    float* cell = &table[g >> 2].q[g & 3ull];
-    double q = (double)*cell;
-    for (int k = i; k < len; ++k)
-      if (group[j + k] == g) {
-        q = q + lr * (target[env[j + k]] - q);                             // Agent/main.py:43
-        done |= 1ull << k;
-      }
-    *cell = (float)q;
-  }
+  if (!first || (g >> drop_bit) != 0ull) return;                           // folded in by an earlier update / dropped
+  float* cell = &table[g >> 2].q[g & 3ull];
+  double q = (double)*cell;
+  for (int k = 0; k <= fwd; ++k)
+    if (group[j + k] == g) q = q + lr * (target[env[j + k]] - q);          // Agent/main.py:43, env order
+  *cell = (float)q;
 }
 
 __global__ __launch_bounds__(kBlock) void k_det_apply_long(q2048_slot* table, u64* group,
