@@ -876,18 +876,28 @@ __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u
                                                       const uint32_t* env, const double* target,
                                                       int64_t B, double lr, int drop_bit, u64 run_mask,
                                                       u64* longs) {
-  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // the block's 256 sorted words and kDetRun neighbours on either side, staged once: every
+  // update scans its run (tens of words) and that traffic belongs in LDS, not in the L1
+  __shared__ u64 tile[kBlock + 2 * kDetRun];
+  const int64_t base = (int64_t)blockIdx.x * kBlock;
+  for (int t = threadIdx.x; t < kBlock + 2 * kDetRun; t += kBlock) {
+    const int64_t at = base - kDetRun + t;
+    tile[t] = (at >= 0 && at < B) ? group[at] : 0ull;
+  }
+  __syncthreads();
+  const int64_t j = base + threadIdx.x;
   if (j >= B) return;
-  const u64 g = group[j];
-  // every update looks at its own run (neighbours in the sorted array, cached): is an earlier
-  // update of the run in the same group (then that one folds this one in), how far does the run go
+  const u64* w = tile + kDetRun + threadIdx.x;           // w[k] = group[j + k], |k| <= kDetRun
+  const u64 g = w[0];
+  // is an earlier update of the run in the same group (then that one folds this one in), and how
+  // far does the run go
   bool first = true;
   int back = 0, fwd = 0;
-  while (back < kDetRun && j - back - 1 >= 0 && ((group[j - back - 1] ^ g) & run_mask) == 0ull) {
-    first = first && group[j - back - 1] != g;
+  while (back < kDetRun && j - back - 1 >= 0 && ((w[-back - 1] ^ g) & run_mask) == 0ull) {
+    first = first && w[-back - 1] != g;
     ++back;
   }
-  while (fwd < kDetRun && j + fwd + 1 < B && ((group[j + fwd + 1] ^ g) & run_mask) == 0ull) ++fwd;
+  while (fwd < kDetRun && j + fwd + 1 < B && ((w[fwd + 1] ^ g) & run_mask) == 0ull) ++fwd;
   if (back + fwd + 1 > kDetRun) {    // a long run (every update of it sees that): the wave kernel's
     if (back == 0)                   // its head lists it; at most B / 65 such runs, no overflow
       longs[1ull + atomicAdd(&longs[0], 1ull)] = (u64)j;
@@ -897,7 +907,7 @@ __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u
   float* cell = &table[g >> 2].q[g & 3ull];
   double q = (double)*cell;
   for (int k = 0; k <= fwd; ++k)
-    if (group[j + k] == g) q = q + lr * (target[env[j + k]] - q);          // Agent/main.py:43, env order
+    if (w[k] == g) q = q + lr * (target[env[j + k]] - q);                  // Agent/main.py:43, env order
   *cell = (float)q;
 }
 
