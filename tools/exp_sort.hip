@@ -32,6 +32,25 @@ static void run(const char* name, u64* kin, u64* kout, uint32_t* vin, uint32_t* 
 }
 
 template <class Config>
+static void run16(const char* name, uint16_t* kin, uint16_t* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned bits) {
+  size_t bytes = 0;
+  CK((rocprim::radix_sort_pairs<Config>(nullptr, bytes, kin, kout, vin, vout, n, 0u, bits, (hipStream_t)0)));
+  void* tmp;
+  CK(hipMalloc(&tmp, bytes + 256));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) CK((rocprim::radix_sort_pairs<Config>(tmp, bytes, kin, kout, vin, vout, n, 0u, bits, (hipStream_t)0)));
+  CK(hipEventRecord(e0, 0));
+  const int reps = 20;
+  for (int r = 0; r < reps; ++r) CK((rocprim::radix_sort_pairs<Config>(tmp, bytes, kin, kout, vin, vout, n, 0u, bits, (hipStream_t)0)));
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  std::printf("{\"config\": \"%s\", \"n\": %zu, \"bits\": %u, \"us_per_sort\": %.1f}\n", name, n, bits, ms * 1e3 / reps);
+  std::fflush(stdout);
+  CK(hipFree(tmp));
+}
+
+template <class Config>
 static void run32(const char* name, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned bits) {
   size_t bytes = 0;
   CK((rocprim::radix_sort_pairs<Config>(nullptr, bytes, kin, kout, vin, vout, n, 0u, bits, (hipStream_t)0)));
@@ -79,6 +98,18 @@ int main(int argc, char** argv) {
   run<Cfg<1024, 8, 8, R::match>>("1024x8 8b match", kin, kout, vin, vout, n, bits);
   run<Cfg<1024, 2, 8, R::match>>("1024x2 8b match", kin, kout, vin, vout, n, bits);
   run<Cfg<1024, 4, 7, R::match>>("1024x4 7b match", kin, kout, vin, vout, n, bits);
+  {  // 16-bit keys: the deterministic mode only needs the low 16 bits of the group word sorted
+    uint16_t *k16, *k16o;
+    CK(hipMalloc(&k16, n * 2)); CK(hipMalloc(&k16o, n * 2));
+    std::vector<uint16_t> kk(n);
+    for (size_t i = 0; i < n; ++i) kk[i] = (uint16_t)k[i];
+    CK(hipMemcpy(k16, kk.data(), n * 2, hipMemcpyHostToDevice));
+    run16<rocprim::default_config>("u16 keys, default", k16, k16o, vin, vout, n, 16);
+    run16<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 8192>>("u16 keys, default onesweep", k16, k16o, vin, vout, n, 16);
+    run16<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<1024, 4>, 8, R::match>, 8192>>("u16 keys, 1024x4 8b match", k16, k16o, vin, vout, n, 16);
+    run16<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<512, 8>, 8, R::match>, 8192>>("u16 keys, 512x8 8b match", k16, k16o, vin, vout, n, 16);
+    run16<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<1024, 8>, 8, R::match>, 8192>>("u16 keys, 1024x8 8b match", k16, k16o, vin, vout, n, 16);
+  }
   // 32-bit keys (tables of up to 2^29 slots: slot << 2 | action, + the drop bit, fit)
   if (bits <= 32) {
     uint32_t* k32 = reinterpret_cast<uint32_t*>(kin);
