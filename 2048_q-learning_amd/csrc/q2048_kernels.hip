@@ -793,9 +793,9 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
 // ---------------------------------------------------------------------------------------------
 // deterministic mode.  One step = phase 1 (every env acts on the table as it is at the start of
 // the step and emits where its update goes and its TD target), a stable radix sort of the updates
-// by (row slot, action) -- rocPRIM's device radix sort over the cap_log2 + 3 bits that are
-// populated: a standard primitive, not hand-written here -- and phase 2 (each (slot, action) group
-// applies its updates in env order).  Nothing in it depends on how lanes are scheduled.
+// by the low bits of (row slot, action) -- rocPRIM's device radix sort, two 8-bit passes: a
+// standard primitive, not hand-written here -- and phase 2 (each (slot, action) group applies its
+// updates in env order).  Nothing in it depends on how lanes are scheduled.
 // ---------------------------------------------------------------------------------------------
 template <int N, int ENV>
 __global__ __launch_bounds__(kBlock) void k_det_phase1(

@@ -253,7 +253,8 @@ int q2048_fused_rollout_log(uint8_t *boards, q2048_aux *aux, q2048_slot *table, 
  *            START of the step (phase 1 writes no Q value; it creates the rows of s and s' like
  *            update_q_value does, Agent/main.py:41-43) and emits its update: (row slot, action)
  *            and the TD target reward + gamma * max Q(s') * (1 - done) (:42);
- *   sort     the updates are sorted by (slot, action) on the device, env order kept inside a group;
+ *   sort     the updates are sorted on the device, stably, by the low 16 bits of (slot, action):
+ *            the updates of a group end up in one short run, in env order;
  *   phase 2  every group applies Q[s][a] += lr * (target - Q[s][a]) (:43) in env order (double
  *            precision inside a group, one rounding to float32; for a group of one that is the
  *            reference update exactly).
