@@ -24,6 +24,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def release_cached_device_memory():
+    """Tests that start child processes on the same GPU first hand this process's cached blocks
+    (earlier tests leave up to 128 GiB of freed tables in torch's allocator) back to the device."""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def ulp32(x):
     return np.spacing(np.abs(np.asarray(x, dtype=np.float32)).astype(np.float32))
 
@@ -1459,6 +1468,7 @@ def test_bench_self_launched_two_ranks_share_one_gpu():
     own two ranks (Q2048_DIST_BACKEND=gloo lets both sit on the one GPU of this box), each owns
     half of the global env ids and its own table replica, and rank 0 prints ONE line whose
     statistics are the all-reduced whole-job numbers.  (RCCL itself needs two GPUs: never run here.)"""
+    release_cached_device_memory()
     import subprocess
     import sys
 
@@ -1487,6 +1497,7 @@ def test_bench_under_torchrun_one_rank_drives_rccl():
     its process group even when it is alone, so this is the N > 1 code path end to end on RCCL --
     `init_process_group("nccl", device_id=...)`, the statistics all-reduce on the side stream, the MAX
     all-reduce of the region times, the barriers -- with the one rank a one-GPU box has."""
+    release_cached_device_memory()
     import socket
     import subprocess
     import sys
@@ -1549,6 +1560,7 @@ def test_no_learn_rollout_reads_but_never_writes(pkg, O, n):
 def test_train_save_then_evaluate_scripts(tmp_path):
     """`train.py --save` writes the learner, `evaluate.py` plays it greedily without learning and
     `train.py --resume` continues from it (the README's train / evaluate / models layout)."""
+    release_cached_device_memory()
     import subprocess
     import sys
 
@@ -1573,6 +1585,7 @@ def test_train_save_then_evaluate_scripts(tmp_path):
 def test_train_self_launched_two_ranks_share_one_gpu(tmp_path):
     """`python train.py --gpus 2`: two self-launched ranks (gloo, both on this box's one GPU), each
     with its shard of the env ids and its own table; rank 0's CSV holds the all-reduced numbers."""
+    release_cached_device_memory()
     import csv
     import subprocess
     import sys
