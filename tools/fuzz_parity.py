@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Confidence run (not part of the test suite): the independent-lane parity check of
+tests/test_gpu_parity.py over more seeds, both geometries, every env profile, deferred writes on and
+off, random launch splits.  Boards and aux bit-exact, every Q row within rtol 1e-5."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("2048_q-learning_amd")
+from oracle import oracle as O  # noqa: E402  (the checker)
+
+dev = "cuda:0"
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+cases = 0
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
+    n = int(rng.choice([4, 5]))
+    B, steps = int(rng.integers(50, 260)), int(rng.integers(100, 500))
+    seed, id0 = int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 2 ** 40))
+    eps, lr, gamma = float(rng.choice([0.0, 0.05, 0.3, 1.0])), float(rng.choice([0.1, 0.5])), float(rng.choice([0.9, 0.99]))
+    profile = str(rng.choice(["shaped", "nopenalty"]))
+    reset_shaping = bool(rng.integers(0, 2))
+    bits = int(rng.choice([0, 1 << 14]))                       # deferred same-state writes on / off
+    strict = bool(rng.integers(0, 2))
+    flags = (O.ENV_DQN if profile == "nopenalty" else 0) | (O.ENV_RESET_SHAPING if reset_shaping else 0)
+    envs = O.envs_init(B, n, seed, id0)
+    agents = [O.Agent(100, 4, lr, gamma, eps, n=n) for _ in range(B)]
+    for i in range(B):
+        O.rollout(envs[i:i + 1], agents[i], steps, seed, id0 + i, 0, env_flags=flags)
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=dev, profile=profile,
+                                 reset_shaping_state=reset_shaping)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                      capacity_log2=19, seed=seed, env_id0=id0, device=dev, independent=True,
+                                      board_size=n, strict_td=strict)
+    agent.experiment_bits = bits
+    left = steps
+    while left > 0:
+        k = int(min(left, rng.integers(1, 200)))
+        agent.fused_rollout(env, k)
+        left -= k
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :n * n]), (trial, "boards")
+    f = env.aux_fields()
+    assert np.array_equal(f["score"], envs["score"]) and np.array_equal(f["episode"], envs["episode"]), (trial, "aux")
+    worst = 0.0
+    for i, oa in enumerate(agents):
+        keys, vals = oa.dump()
+        got = agent.q_values(torch.from_numpy(keys).to(dev), env_id=id0 + i).cpu().numpy()
+        assert np.allclose(got, vals, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(vals).max()))), (trial, i)
+        worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
+    assert agent.table_size() == sum(len(a) for a in agents) and agent.check_status() == 0
+    cases += 1
+    print(f"trial {trial}: {n}x{n} B={B} steps={steps} eps={eps} profile={profile} reset_shaping={reset_shaping} "
+          f"strict={strict} bits={bits:#x}: ok, worst relative Q error {worst:.2e}", flush=True)
+print(f"{cases} cases passed")
