@@ -15,7 +15,6 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "q2048.h"
 #include "q2048_core5.hpp"
@@ -793,15 +792,21 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
 // ---------------------------------------------------------------------------------------------
 // deterministic mode.  One step = phase 1 (every env acts on the table as it is at the start of
 // the step and emits where its update goes and its TD target), a stable radix sort of the updates
-// by the low bits of (row slot, action) -- rocPRIM's device radix sort, two 8-bit passes: a
-// standard primitive, not hand-written here -- and phase 2 (each (slot, action) group applies its
-// updates in env order).  Nothing in it depends on how lanes are scheduled.
+// by the low bits of (row slot, action) -- two 8-bit passes of the radix partition below -- and
+// phase 2 (each (slot, action) group applies its updates in env order).  Nothing in it depends on how lanes are scheduled.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kNoCarry = 0xffffffffu;
+// the four values of a slot whose index is known: one 16-byte agent-scope request
+__device__ __forceinline__ Row ld_row(const q2048_slot* s) {
+  const u32x4 v = ld16_agent(&s->q[0]);
+  return Row{bits_f32(v.x), bits_f32(v.y), bits_f32(v.z), bits_f32(v.w)};
+}
 template <int N, int ENV>
 __global__ __launch_bounds__(kBlock) void k_det_phase1(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
-    uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, uint32_t* env_out,
-    double* target_out, int drop_bit, u64* longs, int64_t* stats_i, double* stats_f, uint32_t* status) {
+    uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, double* target_out,
+    uint32_t* carry, int use_carry, int drop_bit, u64* longs, int64_t* stats_i, double* stats_f,
+    uint32_t* status) {
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
   stats_clear(bs);
@@ -813,23 +818,34 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
     const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
     Aux a = ld_aux(aux, i);
     const auto key_s = state_key(b, salt, status);
-    Row q, qn;
-    bool ins_s = false, ins_n = false, dropped = false;
-    int64_t slot_s = probe_find(table, mask, key_s, q, ins_s);
-    if (slot_s < 0 && slot_s != kNoSlot) slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
-    if (slot_s < 0) { dropped = true; atomicOr(status, Q2048_STATUS_TABLE_FULL); }
     const Draws x = draws(seed, id, ctr, kStreamStep);
     Draws y{0u, 0u, 0u, 0u};
     if constexpr ((ENV & kEnvDqn) != 0) y = draws(seed, id, ctr, kStreamOver);
+    Row q{0.f, 0.f, 0.f, 0.f}, qn;
+    bool ins_s = false, ins_n = false, dropped = false;
+    // s is the s' of the step before unless an episode began in between: its slot was found then
+    // (rows never move), so there is no probe -- and the row itself is needed by greedy lanes only
+    // (at epsilon 0.95: one scattered request per step less for 19 lanes of 20)
+    const uint32_t held = use_carry ? carry[i] : kNoCarry;
+    int64_t slot_s;
+    if (held != kNoCarry) {
+      slot_s = (int64_t)held;
+      if (!(draw_uniform(x.x0) < eps)) q = ld_row(&table[slot_s]);
+    } else {
+      slot_s = probe_find(table, mask, key_s, q, ins_s);
+      if (slot_s < 0 && slot_s != kNoSlot) slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
+      if (slot_s < 0) { dropped = true; atomicOr(status, Q2048_STATUS_TABLE_FULL); }
+    }
     bool explored;
     const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);     // main.py:92
     const StepOut o = env_step_profile<ENV>(b, a, act, x.x2, x.x3, y.x0, y.x1);         // :93
     const auto key_n = state_key(b, salt, status);
-    const int64_t slot_n = probe_find(table, mask, key_n, qn, ins_n);                   // :41
-    if (slot_n < 0 && slot_n != kNoSlot) probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
-    // the group of this update: (slot of s, action); a dropped one sorts behind every group
+    int64_t slot_n = probe_find(table, mask, key_n, qn, ins_n);                         // :41
+    if (slot_n < 0 && slot_n != kNoSlot) slot_n = probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
+    carry[i] = (!o.done && slot_n >= 0 && (u64)slot_n < (u64)kNoCarry) ? (uint32_t)slot_n : kNoCarry;
+    // the group of this update: (slot of s, action); a dropped one sorts behind every group.  The
+    // sort is stable and this array is in env order, so env order survives without an index
     group_out[i] = dropped ? (1ull << drop_bit) : (((u64)slot_s << 2) | (u64)act);
-    env_out[i] = (uint32_t)i;
     target_out[i] = (double)o.reward +
                     (gamma * (double)max4(qn.q0, qn.q1, qn.q2, qn.q3) * (o.done ? 0.0 : 1.0));  // :42
     if (o.done) {
@@ -854,6 +870,151 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
   stats_flush(bs, stats_i, stats_f);
 }
 
+// The sort: least-significant-digit radix passes of 8 bits over (group, target) pairs, each pass a
+// stable partition in three launches.  Tiles of kSortTile pairs, one workgroup each:
+//   k_sort_count    per-tile digit histogram -> cnt[digit][tile]
+//   k_sort_scan     one workgroup per digit: exclusive scan of its row over the tiles (in place)
+//                   and the row total
+//   k_sort_scatter  ranks the tile's pairs stably (a wave walks its 512 pairs 64 at a time; the
+//                   lanes of a round that hold the same digit find each other with eight ballots),
+//                   orders them by digit in LDS and writes every digit's pairs of the tile as one
+//                   contiguous piece (8 pairs = 128 bytes on average) at
+//                   [pairs of smaller digits] + [same digit, earlier tiles].
+// A library sort (rocPRIM onesweep) took 57 us for the two passes over 2^20 pairs -- eleven
+// launches, five of them fills of its look-back state; this one takes six launches and no fills,
+// and its workspace is sized without a device.
+constexpr int kSortTile = 2048;
+constexpr int kSortRounds = kSortTile / kBlock;     // pairs per thread
+constexpr int kSortWaves = kBlock / 64;
+static_assert(kBlock == 256, "one thread per digit value");
+
+__device__ __forceinline__ u64 match_digit(uint32_t d, bool active) {
+  u64 m = __ballot(active);
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    const bool one = ((d >> bit) & 1u) != 0u;
+    const u64 v = __ballot(one);
+    m &= one ? v : ~v;
+  }
+  return m;                                          // the active lanes that hold digit d
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t x = __shfl_up(v, d);
+    if (lane >= (uint32_t)d) v += x;
+  }
+  return v;
+}
+// exclusive scan over the block's 256 values; `ws` = kSortWaves words of LDS
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, volatile uint32_t* ws) {
+  const uint32_t incl = wave_incl_scan(v);
+  const uint32_t w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 63u) ws[w] = incl;
+  __syncthreads();
+  uint32_t off = 0;
+  for (uint32_t k = 0; k < w; ++k) off += ws[k];
+  __syncthreads();
+  return off + incl - v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sort_count(const u64* keys, int64_t B, int shift,
+                                                       uint32_t dmask, uint32_t* cnt, int64_t T) {
+  __shared__ uint32_t h[kBlock];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+  for (int r = 0; r < kSortRounds; ++r) {
+    const int64_t idx = base + r * kBlock + threadIdx.x;
+    if (idx < B) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  cnt[(int64_t)threadIdx.x * T + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void k_sort_scan(uint32_t* cnt, int64_t T, uint32_t* total) {
+  __shared__ uint32_t ws[kSortWaves];
+  uint32_t* row = cnt + (int64_t)blockIdx.x * T;
+  uint32_t carry = 0u;
+  for (int64_t t0 = 0; t0 < T; t0 += kBlock) {
+    const int64_t t = t0 + threadIdx.x;
+    const uint32_t v = t < T ? row[t] : 0u;
+    const uint32_t ex = block_excl_scan(v, ws);
+    if (t < T) row[t] = carry + ex;
+    if (threadIdx.x == kBlock - 1) ws[0] = ex + v;   // the chunk's sum (block_excl_scan ended on a barrier)
+    __syncthreads();
+    carry += ws[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sort_scatter(const u64* kin, const u64* vin, u64* kout,
+                                                         u64* vout, int64_t B, int shift, uint32_t dmask,
+                                                         const uint32_t* tile_before,
+                                                         const uint32_t* total, int64_t T) {
+  __shared__ u64 sk[kSortTile];
+  __shared__ u64 sv[kSortTile];
+  __shared__ uint32_t wcount[kSortWaves][kBlock];   // per wave and digit: pairs seen so far -> pairs of earlier waves
+  __shared__ uint32_t first[kBlock];                // where the digit's pairs start within the tile
+  __shared__ uint32_t dest[kBlock];                 // global index of the digit's piece minus first[]
+  __shared__ uint32_t ws[kSortWaves];
+  volatile uint32_t(*wc)[kBlock] = wcount;
+  const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+#pragma unroll
+  for (int k = 0; k < kSortWaves; ++k) wc[k][tid] = 0u;
+  __syncthreads();
+  // wave w owns pairs [w * 512, (w + 1) * 512) of the tile, round r lane l the pair r * 64 + l of them
+  const int64_t base = (int64_t)blockIdx.x * kSortTile + (int64_t)w * (kSortTile / kSortWaves);
+  u64 k[kSortRounds], v[kSortRounds];
+  uint32_t meta[kSortRounds];                        // digit << 16 | rank among the wave's pairs of the digit
+#pragma unroll
+  for (int r = 0; r < kSortRounds; ++r) {
+    const int64_t idx = base + r * 64 + lane;
+    k[r] = idx < B ? kin[idx] : 0ull;
+    v[r] = idx < B ? vin[idx] : 0ull;
+  }
+#pragma unroll
+  for (int r = 0; r < kSortRounds; ++r) {
+    const bool act = base + r * 64 + lane < B;
+    const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
+    const u64 m = match_digit(d, act);
+    const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t seen = wc[w][d];
+    if (act && before == 0u) wc[w][d] = seen + (uint32_t)__popcll(m);
+    meta[r] = (d << 16) | (seen + before);
+  }
+  __syncthreads();
+  {                                                  // thread = digit
+    const uint32_t c0 = wc[0][tid], c1 = wc[1][tid], c2 = wc[2][tid], c3 = wc[3][tid];
+    wc[0][tid] = 0u; wc[1][tid] = c0; wc[2][tid] = c0 + c1; wc[3][tid] = c0 + c1 + c2;
+    const uint32_t in_tile = block_excl_scan(c0 + c1 + c2 + c3, ws);
+    const uint32_t smaller = block_excl_scan(total[tid], ws);
+    first[tid] = in_tile;
+    dest[tid] = smaller + tile_before[(int64_t)tid * T + blockIdx.x] - in_tile;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortRounds; ++r)
+    if (base + r * 64 + lane < B) {
+      const uint32_t d = meta[r] >> 16;
+      const uint32_t at = first[d] + wc[w][d] + (meta[r] & 0xffffu);
+      sk[at] = k[r];
+      sv[at] = v[r];
+    }
+  __syncthreads();
+  const int64_t left = B - (int64_t)blockIdx.x * kSortTile;
+  const uint32_t n_tile = left < kSortTile ? (uint32_t)left : (uint32_t)kSortTile;
+  for (uint32_t j = tid; j < n_tile; j += kBlock) {
+    const u64 kk = sk[j];
+    const uint32_t at = dest[(uint32_t)(kk >> shift) & dmask] + j;
+    kout[at] = kk;
+    vout[at] = sv[j];
+  }
+}
+
 // Phase 2.  The updates arrive sorted -- stably, so env order survives -- by the LOW `sort_bits`
 // bits of group = (slot << 2) | action only: slots are hash values, so 16 bits (two radix passes
 // instead of five) already cut 2^20 updates into ~65 000 runs of ~16, and inside a run the
@@ -873,9 +1034,8 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
 constexpr int kDetRun = 64;
 constexpr u64 kDetDone = 1ull << 63;
 __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u64* group,
-                                                      const uint32_t* env, const double* target,
-                                                      int64_t B, double lr, int drop_bit, u64 run_mask,
-                                                      u64* longs) {
+                                                      const double* target, int64_t B, double lr,
+                                                      int drop_bit, u64 run_mask, u64* longs) {
   // the block's 256 sorted words and kDetRun neighbours on either side, staged once: every
   // update scans its run (tens of words) and that traffic belongs in LDS, not in the L1
   __shared__ u64 tile[kBlock + 2 * kDetRun];
@@ -907,14 +1067,13 @@ __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u
   float* cell = &table[g >> 2].q[g & 3ull];
   double q = (double)*cell;
   for (int k = 0; k <= fwd; ++k)
-    if (w[k] == g) q = q + lr * (target[env[j + k]] - q);                  // Agent/main.py:43, env order
+    if (w[k] == g) q = q + lr * (target[j + k] - q);                       // Agent/main.py:43, env order
   *cell = (float)q;
 }
 
 __global__ __launch_bounds__(kBlock) void k_det_apply_long(q2048_slot* table, u64* group,
-                                                           const uint32_t* env, const double* target,
-                                                           int64_t B, double lr, int drop_bit,
-                                                           u64 run_mask, const u64* longs) {
+                                                           const double* target, int64_t B, double lr,
+                                                           int drop_bit, u64 run_mask, const u64* longs) {
   const u64 n_long = longs[0];
   const uint32_t lane = threadIdx.x & 63u;
   const u64 waves = (u64)gridDim.x * (kBlock / 64);
@@ -942,7 +1101,7 @@ __global__ __launch_bounds__(kBlock) void k_det_apply_long(q2048_slot* table, u6
       for (int64_t k = cur; k < hi; ++k)
         if (group[k] == g) {
           a = a * (1.0 - lr);
-          b = b * (1.0 - lr) + lr * target[env[k]];
+          b = b * (1.0 - lr) + lr * target[k];
           group[k] = g | kDetDone;
         }
 #pragma unroll
@@ -1478,33 +1637,20 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
   return launch_status();
 }
 
-// workspace of q2048_det_rollout: double-buffered (group, env) pairs, targets, the list of long
-// groups, rocPRIM's temporary storage; every part 256-byte aligned
-// rocPRIM would merge-sort anything up to 1 Mi items (ten small kernels, ~150 us for 1 Mi 64-bit
-// keys); the least-significant-digit radix passes over the cap_log2 + 3 populated bits are ~3x
-// faster, so the merge path is limited to batches that fit a couple of blocks
-// and of the onesweep settings tried (tools/exp_sort.hip, profiles/r02_sort_configs.jsonl: 2^20 pairs
-// over 33 bits) blocks of 1024 x 4 items, 8 bits per pass, wave-match ranking are the fastest:
-// 133 us against 156 for the library's default and 194 for its merge sort
-using DetSortConfig = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<1024, 4>, 8,
-                                        rocprim::block_radix_rank_algorithm::match>,
-    8192>;
-struct DetLayout { size_t group[2], env[2], target, longs, sort, sort_bytes, total; };
-static int det_layout(int64_t B, int cap_log2, DetLayout& L) {
+// workspace of q2048_det_rollout: double-buffered (group, target) pairs, the slot every env holds
+// for its next step, the list of long groups, the sort's per-tile digit counts and digit totals;
+// every part 256-byte aligned
+struct DetLayout { size_t group[2], target[2], carry, longs, cnt, total_cnt, total; int64_t tiles; };
+static int det_layout(int64_t B, int, DetLayout& L) {
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t at = 0;
   for (int k = 0; k < 2; ++k) { L.group[k] = at; at += up((size_t)B * 8); }
-  for (int k = 0; k < 2; ++k) { L.env[k] = at; at += up((size_t)B * 4); }
-  L.target = at; at += up((size_t)B * 8);
+  for (int k = 0; k < 2; ++k) { L.target[k] = at; at += up((size_t)B * 8); }
+  L.carry = at; at += up((size_t)B * 4);
   L.longs = at; at += up(((size_t)B / (kDetRun + 1) + 2) * 8);
-  L.sort_bytes = 0;
-  if (rocprim::radix_sort_pairs<DetSortConfig, u64*, u64*, uint32_t*, uint32_t*>(
-          nullptr, L.sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)B, 0u,
-          (unsigned)(cap_log2 + 3), (hipStream_t)0) != hipSuccess)
-    return Q2048_ERR_LAUNCH;
-  L.sort = at; at += up(L.sort_bytes);
+  L.tiles = (B + kSortTile - 1) / kSortTile;
+  L.cnt = at; at += up((size_t)L.tiles * kBlock * 4);
+  L.total_cnt = at; at += up((size_t)kBlock * 4);
   L.total = at;
   return Q2048_OK;
 }
@@ -1522,7 +1668,7 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
                       double* stats_f, uint32_t* status, void* workspace, int64_t workspace_bytes,
                       void* stream) {
   if (int e = check_batch(B, n)) return e;
-  if (B > 0x7fffffffll) return Q2048_ERR_SIZE;                       // env indices are 32-bit here
+  if (B > 0x7fffffffll) return Q2048_ERR_SIZE;                       // one sort of at most 2^31 updates
   if (int e = check_table(table, cap_log2)) return e;
   if (!boards || !aux || !status || !workspace) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux) || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return Q2048_ERR_ALIGN;
@@ -1534,8 +1680,10 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   if (workspace_bytes < (int64_t)L.total) return Q2048_ERR_SIZE;
   char* ws = static_cast<char*>(workspace);
   u64* group[2] = {reinterpret_cast<u64*>(ws + L.group[0]), reinterpret_cast<u64*>(ws + L.group[1])};
-  uint32_t* env[2] = {reinterpret_cast<uint32_t*>(ws + L.env[0]), reinterpret_cast<uint32_t*>(ws + L.env[1])};
-  double* target = reinterpret_cast<double*>(ws + L.target);
+  double* target[2] = {reinterpret_cast<double*>(ws + L.target[0]), reinterpret_cast<double*>(ws + L.target[1])};
+  uint32_t* carry = reinterpret_cast<uint32_t*>(ws + L.carry);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + L.cnt);
+  uint32_t* total_cnt = reinterpret_cast<uint32_t*>(ws + L.total_cnt);
   u64* longs = reinterpret_cast<u64*>(ws + L.longs);
   const hipStream_t s = (hipStream_t)stream;
   const u64 mask = (1ull << cap_log2) - 1ull;
@@ -1548,16 +1696,22 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   const u64 run_mask = (1ull << sort_bits) - 1ull;
   for (int64_t t = 0; t < steps; ++t) {
     Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
-                     ctr0 + (uint32_t)t, flags, group[0], env[0], target, drop_bit, longs, stats_i,
-                     stats_f, status);
-    size_t sort_bytes = L.sort_bytes;
-    if (rocprim::radix_sort_pairs<DetSortConfig>(ws + L.sort, sort_bytes, group[0], group[1], env[0], env[1], (size_t)B,
-                                  0u, (unsigned)sort_bits, s) != hipSuccess)
-      return Q2048_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_det_apply, dim3(grid_for(B)), dim3(kBlock), 0, s, table, group[1], env[1], target,
-                       B, lr, drop_bit, run_mask, longs);
-    hipLaunchKernelGGL(k_det_apply_long, dim3(256), dim3(kBlock), 0, s, table, group[1], env[1], target, B,
-                       lr, drop_bit, run_mask, longs);
+                     ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), drop_bit, longs,
+                     stats_i, stats_f, status);
+    int cur = 0;                                     // which buffer holds the pairs
+    for (int lo = 0; lo < sort_bits; lo += 8, cur ^= 1) {
+      const uint32_t dmask = sort_bits - lo >= 8 ? 255u : (1u << (sort_bits - lo)) - 1u;
+      hipLaunchKernelGGL(k_sort_count, dim3((unsigned)L.tiles), dim3(kBlock), 0, s, group[cur], B, lo, dmask,
+                         cnt, L.tiles);
+      hipLaunchKernelGGL(k_sort_scan, dim3(kBlock), dim3(kBlock), 0, s, cnt, L.tiles, total_cnt);
+      hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)L.tiles), dim3(kBlock), 0, s, group[cur],
+                         reinterpret_cast<const u64*>(target[cur]), group[cur ^ 1],
+                         reinterpret_cast<u64*>(target[cur ^ 1]), B, lo, dmask, cnt, total_cnt, L.tiles);
+    }
+    hipLaunchKernelGGL(k_det_apply, dim3(grid_for(B)), dim3(kBlock), 0, s, table, group[cur], target[cur], B, lr,
+                       drop_bit, run_mask, longs);
+    hipLaunchKernelGGL(k_det_apply_long, dim3(256), dim3(kBlock), 0, s, table, group[cur], target[cur], B, lr,
+                       drop_bit, run_mask, longs);
     if (int e = launch_status()) return e;
   }
   return Q2048_OK;
