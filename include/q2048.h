@@ -261,8 +261,9 @@ int q2048_fused_rollout_log(uint8_t *boards, q2048_aux *aux, q2048_slot *table, 
  * The result equals the reference agent fed the step's transitions in env order against the
  * step-start table, for any B, bit-identically from run to run.  `steps` steps per call, draws of
  * counter ctr0 + t; flags as q2048_fused_rollout (TD_CAS / PLAY_ONLY have no meaning here).
- * `workspace`: caller-owned device scratch of q2048_det_workspace_bytes(B, cap_log2) bytes,
- * 256-byte aligned (B < 2^31). */
+ * `workspace`: caller-owned device scratch of q2048_det_workspace_bytes(B, cap_log2) bytes
+ * (about 36 bytes per env; host arithmetic, needs no device), 256-byte aligned (B < 2^31).  It
+ * holds no state between calls. */
 int64_t q2048_det_workspace_bytes(int64_t B, int cap_log2);
 int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2, int64_t B,
                       int n, int64_t steps, double eps, double lr, double gamma, uint64_t seed,

@@ -37,6 +37,11 @@ def test_abi_exports_every_declared_symbol(pkg):
                                  None, None, None) == -1
     assert L.q2048_q_choose(16, 99, 16, 4, 4, 0.5, 0, 0, 0, 0, 16, 16, None) == -2  # bad cap_log2
     assert L.q2048_q_choose(16, 20, 16, 4, 4, 1.5, 0, 0, 0, 0, 16, 16, None) == -6  # eps range
+    # the deterministic mode's workspace is host arithmetic: pairs twice over, slots, long-run list, counts
+    small, big = L.q2048_det_workspace_bytes(1, 20), L.q2048_det_workspace_bytes(1 << 20, 32)
+    assert 0 < small < 1 << 20 and small % 256 == 0
+    assert 36 * (1 << 20) <= big <= 40 * (1 << 20) and big % 256 == 0
+    assert L.q2048_det_workspace_bytes(-1, 20) < 0 and L.q2048_det_workspace_bytes(1 << 31, 20) < 0
 
 
 def test_header_structs_match_numpy_layout(pkg):

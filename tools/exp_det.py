@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Measurement tool: env-steps/s of the deterministic mode (q2048_det_rollout: phase 1, device
-radix sort by (row, action), grouped apply) next to the racing fused kernel on the same job."""
+"""Measurement tool: env-steps/s of the deterministic mode (q2048_det_rollout: phase 1, stable
+radix partition by (row, action), grouped apply) next to the racing fused kernel on the same job."""
 import importlib
 import json
 import os
