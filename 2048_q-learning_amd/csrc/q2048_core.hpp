@@ -67,7 +67,9 @@ Q_HD Draws draws(uint64_t seed, uint64_t env_id, uint32_t ctr, uint32_t stream) 
 Q_HD double draw_uniform(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
 Q_HD int draw_action(uint32_t x) { return (int)(x >> 30); }
 Q_HD uint32_t draw_index(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * n) >> 32); }
-Q_HD bool draw_is_four(uint32_t x) { return !(draw_uniform(x) < 0.9); }
+// not (random() < 0.9) (Game2048_env.py:20): x / 2^32 < 0.9 (the double nearest 0.9) holds exactly for
+// x <= 3865470566 (0.9 * 2^32 = 3865470566.4), so the test is an integer compare
+Q_HD bool draw_is_four(uint32_t x) { return x >= 3865470567u; }
 
 // ------------------------------------------------------------------------------------------
 // SWAR helpers on four tile bytes per word.  Every tile byte is <= 0x7f (log2 <= 17 on 4x4).
@@ -75,6 +77,9 @@ Q_HD bool draw_is_four(uint32_t x) { return !(draw_uniform(x) < 0.9); }
 Q_HD uint32_t nz80(uint32_t x) { return (x + 0x7f7f7f7fu) & 0x80808080u; }       // 0x80 per byte != 0
 Q_HD uint32_t z80(uint32_t x) { return ~(x + 0x7f7f7f7fu) & 0x80808080u; }       // 0x80 per byte == 0
 Q_HD uint32_t fill80(uint32_t m) { return (m << 1) - (m >> 7); }                 // 0x80 -> 0xff
+// 0x80 -> 0x7f: as good a select mask as 0xff between words whose bytes are all <= 0x7f (bit 7 is
+// 0 on both sides), one instruction less
+Q_HD uint32_t fill7f(uint32_t m) { return m - (m >> 7); }
 Q_HD uint32_t bsel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
 struct Board { uint32_t r0, r1, r2, r3; };
@@ -108,29 +113,29 @@ Q_HD uint32_t slide_lines(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3
   // compress (:26): pull cells towards c0 while the head cell is empty
 #pragma unroll
   for (int rep = 0; rep < 3; ++rep) {
-    z = fill80(z80(c0));
+    z = fill7f(z80(c0));
     c0 = bsel(z, c1, c0); c1 = bsel(z, c2, c1); c2 = bsel(z, c3, c2); c3 &= ~z;
   }
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
-    z = fill80(z80(c1));
+    z = fill7f(z80(c1));
     c1 = bsel(z, c2, c1); c2 = bsel(z, c3, c2); c3 &= ~z;
   }
-  z = fill80(z80(c2));
+  z = fill7f(z80(c2));
   c2 = bsel(z, c3, c2); c3 &= ~z;
   // merge (:29-40): pair (0,1), then the next unmerged pair, never re-merging a result
   uint32_t e = z80(c0 ^ c1) & nz80(c0);
-  uint32_t m = fill80(e);
+  uint32_t m = fill7f(e);
   c0 += e >> 7;
   const uint32_t s_a = c0 & m;
   c1 = bsel(m, c2, c1); c2 = bsel(m, c3, c2); c3 &= ~m;
   e = z80(c1 ^ c2) & nz80(c1);
-  m = fill80(e);
+  m = fill7f(e);
   c1 += e >> 7;
   const uint32_t s_b = c1 & m;
   c2 = bsel(m, c3, c2); c3 &= ~m;
   e = z80(c2 ^ c3) & nz80(c2);
-  m = fill80(e);
+  m = fill7f(e);
   c2 += e >> 7;
   c3 &= ~m;
   const uint32_t s_c = c2 & m;  // a line that merged at (2,3) merged nowhere else
@@ -200,7 +205,7 @@ Q_HD bool game_over(const Board& b) {
 }
 
 Q_HD uint32_t bytemax(uint32_t a, uint32_t b) {  // per-byte max, bytes <= 0x7f
-  const uint32_t m = fill80(((a | 0x80808080u) - b) & 0x80808080u);
+  const uint32_t m = fill7f(((a | 0x80808080u) - b) & 0x80808080u);
   return bsel(m, a, b);
 }
 Q_HD uint32_t max_log2(const Board& b) {  // np.max(board) (:100), as log2
@@ -256,9 +261,11 @@ Q_HD double log2_ge1(double x) {
 }
 
 // update_and_normalize (:197-205); both log2 arguments are >= 1
+// One logarithm serves both signs: |r - 1| for r < 0 is |r| + 1, the same double (rounding is
+// symmetric), and r + 1 is |r| + 1 for r >= 0 (-0.0 included).
 Q_HD double normalize_reward(double r) {
-  if (r >= 0) return fmin(log2_ge1(r + 1), 10.0);
-  return -fmin(log2_ge1(fabs(r - 1)), 10.0);
+  const double v = fmin(log2_ge1(fabs(r) + 1.0), 10.0);
+  return r >= 0 ? v : -v;
 }
 
 // calculate_reward (:136-184); L = log2(max tile), prev = log2(previous_max), both integers

@@ -455,14 +455,12 @@ __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux*
   store_board(boards, i, B, b, st);
 }
 
-// The 4x4 single-step kernel of the 4-call API: no LDS staging, and a thread can walk several
-// boards, requesting board, aux and action of the next one before it computes the current one.
-// Measured (profiles/r02_env_step.jsonl): one board per thread is the fastest setting, 15.0 us per
-// 1 Mi boards = 4.9 TB/s of the 70 B/step, 100 us per 8 Mi boards = 5.8 TB/s (93 % of the
-// 6.29 TB/s copy ceiling); at 1 Mi boards the ~540 VALU instructions per board and the two-round
-// grid leave the memory system idle for about a quarter of the launch.  Starting every other
-// block 1-8 Ki cycles late (a stagger, so that one half computes while the other loads) measured
-// 15.1 us at best, worse beyond 2 Ki cycles (profiles/r02_env_step_stagger.jsonl): not kept.
+// The 4x4 single-step kernel of the 4-call API for more than one board per thread (experiment
+// bits of q2048_env_step_ex): no LDS staging, and a thread requests board, aux and action of its
+// next board before it computes the current one.  Measured slower than one board per thread
+// (profiles/r02_env_step.jsonl: 14.6 / 15.2 / 16.1 / 19.1 us per 1 Mi boards for 1 / 2 / 4 / 8), as
+// did starting every other block 1-8 Ki cycles late (r02_env_step_stagger.jsonl): k_env_step4
+// below is the default.
 template <int ENV>
 __global__ __launch_bounds__(kBlock) void k_env_step4_pipelined(
     uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, uint64_t seed,
@@ -499,6 +497,44 @@ __global__ __launch_bounds__(kBlock) void k_env_step4_pipelined(
     if (nxt >= B) break;
     i = nxt; bv = bn; av = an; act = actn;
   }
+}
+
+// The same step, one board per thread, without the loop: the setting that measures fastest, and
+// straight-line code spares the next-board addresses, the copies and the loop's branches (37
+// VGPRs instead of 70).  14.7 us per 1 Mi boards = 5.0 TB/s of the 70 B/step, 99.6 us per 8 Mi
+// boards = 5.9 TB/s (94 % of the 6.29 TB/s copy ceiling); a kernel that only moves the same bytes
+// takes 12.07 / 103.5 us (tools/exp_stream_floor.hip).
+template <int ENV>
+__global__ __launch_bounds__(kBlock) void k_env_step4(
+    uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, uint64_t seed,
+    uint64_t env_id0, uint32_t ctr, float* reward, uint8_t* done, uint8_t* max_l2, uint32_t* status) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  const uint4 bv = reinterpret_cast<const uint4*>(boards)[i];
+  const uint4 av = reinterpret_cast<const uint4*>(aux)[i];
+  const uint32_t act = actions[i];
+  // The three loads go out together: testing the action first would put its round trip in front
+  // of the board's and the aux record's (the compiler sinks loads below a branch that does not
+  // need them).  A bad action's lane computes a step it then discards.
+  // The draws need nothing from memory: they are computed while the loads are in flight (the
+  // scheduler would otherwise start with the slide, i.e. with a wait -- at the start of a launch
+  // every wave of the chip sits in that wait at once).
+  Draws x = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamStep);
+  Draws y{0u, 0u, 0u, 0u};
+  if constexpr ((ENV & kEnvDqn) != 0) y = draws(seed, env_id0 + (uint64_t)i, ctr, kStreamOver);
+  asm volatile("" : "+v"(x.x2), "+v"(x.x3), "+v"(y.x0), "+v"(y.x1));   // here, not sunk into the spawn's branch
+  __builtin_amdgcn_sched_barrier(0);
+  Board b{bv.x, bv.y, bv.z, bv.w};
+  Aux a = words_to_aux(Words4{av.x, av.y, av.z, av.w});
+  const StepOut o = env_step_profile<ENV>(b, a, (int)(act & 3u), x.x2, x.x3, y.x0, y.x1);
+  if (act > 3u) {  // rejected, never masked (Game2048_env.py:56-60 would mis-rotate); board and aux stay
+    atomicOr(status, Q2048_STATUS_BAD_ACTION);
+    reward[i] = 0.f; done[i] = 0; max_l2[i] = 0;
+    return;
+  }
+  reinterpret_cast<uint4*>(boards)[i] = make_uint4(b.r0, b.r1, b.r2, b.r3);
+  st_aux(aux, i, a);
+  reward[i] = o.reward; done[i] = o.done; max_l2[i] = o.max_log2;
 }
 
 // legal-move mask (mainDQL_CNN_step2.py:168-174): four trial moves per lane, nothing stored back
@@ -1506,7 +1542,14 @@ static int env_step_impl(uint8_t* boards, q2048_aux* aux, const uint8_t* actions
     const int64_t per_thread = ((flags >> 8) & 15u) ? (int64_t)((flags >> 8) & 15u) : 1;
     int64_t blocks = (B + kBlock * per_thread - 1) / (kBlock * per_thread);
     if (blocks > 0x7fffffff) blocks = 0x7fffffff;
-    if (flags & Q2048_FLAG_ENV_DQN)
+    if (per_thread == 1) {
+      if (flags & Q2048_FLAG_ENV_DQN)
+        hipLaunchKernelGGL(k_env_step4<kEnvDqn>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                           boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status);
+      else
+        hipLaunchKernelGGL(k_env_step4<0>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                           boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status);
+    } else if (flags & Q2048_FLAG_ENV_DQN)
       hipLaunchKernelGGL(k_env_step4_pipelined<kEnvDqn>, dim3((unsigned)blocks), dim3(kBlock), 0,
                          (hipStream_t)stream, boards, aux, actions, B, seed, env_id0, ctr, reward, done,
                          max_log2, status);
