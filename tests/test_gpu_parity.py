@@ -1356,6 +1356,26 @@ def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, n, B, steps
     assert agent.check_status() == 0
 
 
+@pytest.mark.parametrize("B", [1, 63, 2047, 2048, 2049, 4097, 6144])
+def test_deterministic_mode_batch_edges(pkg, O, B):
+    """The partition works on tiles of 2048 updates: batches of one update, of less than a wave, of
+    exactly one and exactly three tiles, and of one update more than a tile, against the oracle
+    (eps = 1: exact trajectories whatever the table holds; lr = 0.5 so that folded groups show)."""
+    seed, id0, eps, lr, gamma, steps = 5, 3, 1.0, 0.5, 0.9, 12
+    env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                      capacity_log2=18, seed=seed, env_id0=id0, device=DEV)
+    agent.deterministic_rollout(env, steps)
+    envs = O.envs_init(B, 4, seed, id0)
+    oa = O.Agent(100, 4, lr, gamma, eps)
+    O.rollout_sync(envs, oa, steps, seed, id0, 0)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16])
+    keys, vals = oa.dump()
+    got = agent.q_values(t8(keys)).cpu().numpy()
+    assert np.allclose(got, vals, rtol=1e-5, atol=1e-6)
+    assert agent.table_size() == len(oa) and agent.check_status() == 0
+
+
 # ---------------------------------------------------------------------------------------------
 # table placement probe
 # ---------------------------------------------------------------------------------------------
