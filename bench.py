@@ -56,7 +56,7 @@ ALGO_BYTES_FUSED_5X5 = 156
 ALGO_BYTES_ROW_TUPLE = 64 + 8 * 16 + 4 * 4 + 6
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
-PMC_TRAFFIC_FILE = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r02_pmc_traffic.json", "r02_pmc_traffic_k20.json")]
 
 
 def parse_args(argv=None):
@@ -103,17 +103,22 @@ def load_launcher():
 
 
 def committed_pmc_traffic(cfg: dict):
-    """(bytes per env-step, source, None) when the committed rocprofv3 PMC passes (profiles/) were
-    taken with this run's configuration, else (None, None, the configuration they were taken with)."""
-    try:
-        with open(PMC_TRAFFIC_FILE) as fh:
-            pmc = json.load(fh)
-    except (OSError, ValueError):
-        return None, None, None
-    have = pmc.get("config", {})
-    if all(have.get(k) == v for k, v in cfg.items()):
-        return pmc["bytes_per_env_step"], pmc["source"], None
-    return None, None, have
+    """(bytes per env-step, source, None) when one of the committed rocprofv3 PMC profiles
+    (profiles/r02_pmc_traffic*.json: the SURVEY protocol's 64-step launches, the driver's single
+    20-step launch) was taken with this run's configuration, else (None, None, the configurations
+    they were taken with)."""
+    seen = []
+    for path in PMC_TRAFFIC_FILES:
+        try:
+            with open(path) as fh:
+                pmc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        have = pmc.get("config", {})
+        if all(have.get(k) == v for k, v in cfg.items()):
+            return pmc["bytes_per_env_step"], pmc["source"], None
+        seen.append(have)
+    return None, None, (seen[0] if len(seen) == 1 else seen) if seen else None
 
 
 def cpu_model() -> str:

@@ -44,6 +44,25 @@ def test_abi_exports_every_declared_symbol(pkg):
     assert L.q2048_det_workspace_bytes(-1, 20) < 0 and L.q2048_det_workspace_bytes(1 << 31, 20) < 0
 
 
+def test_bench_traffic_comes_only_from_a_matching_pmc_profile():
+    """roofline.traffic is a committed counter measurement only for the configuration it was taken
+    with (the protocol's 64-step launches, the driver's single 20-step launch); any other run gets
+    null and the list of configurations that were profiled."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = {"boards": 1048576, "steps_per_launch": 64, "cap_log2": 32, "board_size": 4, "eps": 0.95, "strict_td": False}
+    b64, src, other = bench.committed_pmc_traffic(cfg)
+    assert 150 < b64 < 220 and "rocprofv3" in src and other is None
+    b20, _, _ = bench.committed_pmc_traffic(dict(cfg, steps_per_launch=20))
+    assert 150 < b20 < 240 and b20 != b64
+    none, _, seen = bench.committed_pmc_traffic(dict(cfg, steps_per_launch=16))
+    assert none is None and len(seen) == 2
+    assert bench.committed_pmc_traffic(dict(cfg, board_size=5))[0] is None
+
+
 def test_header_structs_match_numpy_layout(pkg):
     assert pkg.AUX_DTYPE.itemsize == 16
     assert [pkg.AUX_DTYPE.fields[k][1] for k in pkg.AUX_DTYPE.names] == [0, 4, 8, 9, 10, 12]
