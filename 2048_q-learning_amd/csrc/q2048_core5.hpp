@@ -20,7 +20,8 @@ constexpr uint32_t k5All = k5One * 63u;
 
 Q_HD uint32_t nz5(uint32_t x) { return (x + k5Low) & k5High; }    // guard bit set per field != 0
 Q_HD uint32_t z5(uint32_t x) { return ~(x + k5Low) & k5High; }    // guard bit set per field == 0
-Q_HD uint32_t fill5(uint32_t m) { return (m << 1) - (m >> 5); }   // guard bit -> 0x3f field
+// guard bit -> 0x1f: selects between fields whose guard bits are both 0 need no more (as fill7f)
+Q_HD uint32_t fill5(uint32_t m) { return m - (m >> 5); }
 Q_HD uint32_t field5(uint32_t w, int c) { return (w >> (6 * c)) & 63u; }
 
 Q_HD bool operator==(const Board5& a, const Board5& b) {
