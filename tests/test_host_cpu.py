@@ -42,6 +42,16 @@ def test_abi_exports_every_declared_symbol(pkg):
     assert 0 < small < 1 << 20 and small % 256 == 0
     assert 36 * (1 << 20) <= big <= 40 * (1 << 20) and big % 256 == 0
     assert L.q2048_det_workspace_bytes(-1, 20) < 0 and L.q2048_det_workspace_bytes(1 << 31, 20) < 0
+    # q2048_det_rollout validates before it launches anything (fake, aligned, non-null addresses)
+    det = lambda boards, ws, ws_bytes, B=4, n=4, cap=20, eps=0.5: L.q2048_det_rollout(
+        boards, 4096, 8192, cap, B, n, 1, eps, 0.1, 0.9, 0, 0, 0, 0, None, None, 12288, ws, ws_bytes, None)
+    assert det(None, 16384, 1 << 20) == -1                       # null boards
+    assert det(256, None, 1 << 20) == -1                         # null workspace
+    assert det(256, 16384 + 8, 1 << 20) == -3                    # workspace not 256-byte aligned
+    assert det(256, 16384, 16) == -2                             # workspace too small
+    assert det(256, 16384, 1 << 20, n=6) == -4 and det(256, 16384, 1 << 20, cap=3) == -2
+    assert det(256, 16384, 1 << 20, eps=1.5) == -6
+    assert det(256, 16384, 1 << 20, B=0) == 0                    # nothing to do
 
 
 def test_bench_traffic_comes_only_from_a_matching_pmc_profile():
