@@ -14,6 +14,9 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_PKG, "..", "include"))
 LIB_PATH = os.environ.get("Q2048_LIB_PATH") or os.path.join(CSRC, "libq2048_hip.so")  # override: experiments
+# the measurement build (-DQ2048_EXPERIMENTS: extra flag bits 8..23 for ablations and sort widths);
+# tools/ and two parity tests load it explicitly, the package never does
+EXPERIMENTS_LIB_PATH = os.path.abspath(os.path.join(_PKG, "..", "tools", "variants", "libq2048_hip_exp.so"))
 SOURCES = ["q2048_kernels.hip"]
 DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc"]
 
@@ -21,9 +24,10 @@ OK = 0
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
 FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
 FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY, FLAG_NO_LEARN = 8, 16, 32, 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
 ST_HIST0, NSTAT_I = 8, 32
+ST_HIST_BINS, ST_CAS_FALLBACK = 23, 31
 SF_RETURN, SF_RETURN_SQ, SF_REWARD, NSTAT_F = 0, 1, 2, 4
 SIZEOF_AUX, SIZEOF_SLOT, SIZEOF_EPISODE = 16, 32, 48
 
@@ -47,18 +51,35 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile(out: str, defines=(), verbose: bool = False) -> str:
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", *defines,
+           "-I", INCLUDE, "-I", CSRC, "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -shared: builds csrc/libq2048_hip.so in-tree."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-I", INCLUDE, "-I", CSRC, "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    _compile(LIB_PATH, verbose=verbose)
     global _lib
     _lib = None
     return LIB_PATH
+
+
+def build_experiments(force: bool = False, verbose: bool = False) -> str:
+    """The measurement build of the same sources (tools/variants/libq2048_hip_exp.so)."""
+    out = EXPERIMENTS_LIB_PATH
+    if not force and os.path.exists(out):
+        t = os.path.getmtime(out)
+        deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.join(INCLUDE, "q2048.h")]
+        if not any(os.path.getmtime(d) > t for d in deps):
+            return out
+    return _compile(out, defines=("-DQ2048_EXPERIMENTS",), verbose=verbose)
 
 
 # every pointer argument is a device pointer and travels as an integer (c_void_p)
@@ -131,16 +152,13 @@ _SIGNATURES = {
 _lib = None
 
 
-def lib() -> C.CDLL:
-    """Loads the library or raises; never substitutes another implementation."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path: str) -> C.CDLL:
+    """Loads one build of the library and checks its ABI (every symbol, version, struct sizes)."""
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback). "
+            f"{path} is missing: the HIP extension is required (no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the ABI is incomplete
         fn.restype, fn.argtypes = res, args
@@ -148,8 +166,21 @@ def lib() -> C.CDLL:
         raise ImportError(f"ABI version {L.q2048_abi_version()} != {ABI_VERSION}")
     if L.q2048_sizeof_aux() != SIZEOF_AUX or L.q2048_sizeof_slot() != SIZEOF_SLOT:
         raise ImportError("ABI struct sizes changed")
-    _lib = L
     return L
+
+
+def lib() -> C.CDLL:
+    """Loads the library or raises; never substitutes another implementation."""
+    global _lib
+    if _lib is None:
+        _lib = load(LIB_PATH)
+    return _lib
+
+
+def use_experiments_build() -> None:
+    """tools/ and tests only: route this process's calls through the measurement build."""
+    global _lib
+    _lib = load(build_experiments())
 
 
 def claim_timeouts() -> int:

@@ -546,8 +546,8 @@ def stats_dict(si, sf) -> dict:
         "steps": int(si[N.ST_STEPS]), "episodes": ep, "valid_moves": int(si[N.ST_VALID]),
         "score_sum": int(si[N.ST_SCORE]), "inserts": int(si[N.ST_INSERTS]),
         "drops": int(si[N.ST_DROPS]), "explored": int(si[N.ST_EXPLORE]),
-        "cas_retries": int(si[N.ST_CAS_RETRY]),
-        "max_tile_hist": {1 << k: int(v) for k, v in enumerate(si[N.ST_HIST0:N.ST_HIST0 + 24]) if v},
+        "cas_retries": int(si[N.ST_CAS_RETRY]), "cas_fallbacks": int(si[N.ST_CAS_FALLBACK]),
+        "max_tile_hist": {1 << k: int(v) for k, v in enumerate(si[N.ST_HIST0:N.ST_HIST0 + N.ST_HIST_BINS]) if v},
         "return_sum": float(sf[N.SF_RETURN]), "return_sq_sum": float(sf[N.SF_RETURN_SQ]),
         "reward_sum": float(sf[N.SF_REWARD]),
         "mean_return": float(sf[N.SF_RETURN]) / ep if ep else float("nan"),

@@ -491,11 +491,29 @@ Q_HD int eps_greedy(double eps, uint32_t x_eps, uint32_t x_act, float q0, float 
   return explored ? draw_action(x_act) : argmax4(q0, q1, q2, q3);  // :36 / :38
 }
 
-// update_q_value (Agent/main.py:41-43): returns the new Q[s][a] given the current one
+// update_q_value (Agent/main.py:41-43) in the reference's own double arithmetic: no fused
+// multiply-add (CPython rounds the product and the sum separately, and so does the oracle), so the
+// device's doubles equal the oracle's bit for bit and only the final float32 store differs from the
+// reference's float64 dict.
+#if defined(__clang__)
+#define Q2048_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define Q2048_NO_CONTRACT
+#endif
+Q_HD double td_target(float reward, float max_q_next, bool done, double gamma) {
+  Q2048_NO_CONTRACT
+  const double bootstrap = gamma * (double)max_q_next;
+  return (double)reward + bootstrap * (done ? 0.0 : 1.0);                                     // :42
+}
+Q_HD double td_fold(double q, double target, double lr) {
+  Q2048_NO_CONTRACT
+  const double step = lr * (target - q);
+  return q + step;                                                                            // :43
+}
+// returns the new Q[s][a] given the current one
 Q_HD float td_value(float q_sa, float reward, float max_q_next, bool done, double lr,
                     double gamma) {
-  const double target = (double)reward + (gamma * (double)max_q_next * (done ? 0.0 : 1.0));  // :42
-  return (float)((double)q_sa + lr * (target - (double)q_sa));                                // :43
+  return (float)td_fold((double)q_sa, td_target(reward, max_q_next, done, gamma), lr);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -19,6 +19,16 @@
 #include "q2048.h"
 #include "q2048_core5.hpp"
 
+// Measurement variants (write-mode / ablation / sort-width / boards-per-thread bits in flags 8..23)
+// exist only in builds with -DQ2048_EXPERIMENTS (tools/variants/libq2048_hip_exp.so, used by tools/
+// and by the tests that force crowded sort runs).  The shipped library takes the ABI flags of
+// q2048.h and nothing else: any other bit is Q2048_ERR_FLAGS.
+#ifdef Q2048_EXPERIMENTS
+#define Q2048_XBITS(flags, shift, mask) (((flags) >> (shift)) & (mask))
+#else
+#define Q2048_XBITS(flags, shift, mask) 0u
+#endif
+
 namespace {
 using namespace q2048;
 
@@ -119,10 +129,14 @@ __device__ __forceinline__ bool key_eq(const Geo<4>::Key& a, const Geo<4>::Key& 
 __device__ __forceinline__ bool key_eq(const Geo<5>::Key& a, const Geo<5>::Key& b) {
   return a.k0 == b.k0 && a.k1 == b.k1;
 }
-__device__ __forceinline__ u64 key_home(const Geo<4>::Key& k, u64 mask) { return mix64(k.k0) & mask; }
-__device__ __forceinline__ u64 key_home(const Geo<5>::Key& k, u64 mask) {
-  return mix64(k.k0 ^ (k.k1 * 0x9E3779B97F4A7C15ull)) & mask;
+// 64 hash bits of a key: the low ones choose the home slot, the top 16 the deterministic mode's
+// sort bucket (a function of the state alone -- not of where its row ended up)
+__device__ __forceinline__ u64 key_hash(const Geo<4>::Key& k) { return mix64(k.k0); }
+__device__ __forceinline__ u64 key_hash(const Geo<5>::Key& k) {
+  return mix64(k.k0 ^ (k.k1 * 0x9E3779B97F4A7C15ull));
 }
+template <class Key>
+__device__ __forceinline__ u64 key_home(const Key& k, u64 mask) { return key_hash(k) & mask; }
 
 // ---------------------------------------------------------------------------------------------
 // hash table.  Readers use agent-scope relaxed loads (they bypass the per-CU L1, which other
@@ -306,36 +320,44 @@ __device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, co
 //          (s, a) at the same time the last writer wins (never a torn value).
 //   CAS (Q2048_FLAG_TD_CAS)  compare-and-swap loop: a failed swap returns the live value and
 //          the update is recomputed from it, so concurrent updates of one (s, a) serialise -- for
-//          up to kMaxCas attempts, after which the update is stored as in STORE mode.
-//   The other modes are measurement variants selected by experiment bits 8..11 of flags.
+//          up to kMaxCas attempts; an entry contended beyond that takes the update as an atomic
+//          add of (new - last seen): the sample is never lost, only its weight is taken against a
+//          value a few hundred nanoseconds old.  Those fall-backs are counted (Q2048_ST_CAS_FALLBACK).
+//   NONE   nothing is written (Q2048_FLAG_NO_LEARN).
+//   The other modes are measurement variants (Q2048_EXPERIMENTS builds only).
 enum : uint32_t { kTdStorePlain = 0, kTdCas = 1, kTdStoreSc1 = 2, kTdStoreNt = 3, kTdNone = 4,
                   kTdAdd = 6 };
+struct TdCounters { uint32_t retries, fallbacks; };
 __device__ __forceinline__ float td_update(q2048_slot* slot, int a, float guess, float reward,
                                            float max_next, bool done, double lr, double gamma,
-                                           uint32_t& retries, uint32_t mode, int max_cas = kMaxCas) {
+                                           TdCounters& ctrs, uint32_t mode, int max_cas = kMaxCas) {
   unsigned int* addr = reinterpret_cast<unsigned int*>(&slot->q[a]);
   unsigned int expect = f32_bits(guess);
   float nq = td_value(guess, reward, max_next, done, lr, gamma);
   if (mode == kTdStorePlain) { *addr = f32_bits(nq); return nq; }
+  if (mode == kTdNone) return nq;
+#ifdef Q2048_EXPERIMENTS
   if (mode == kTdStoreSc1) {
     __hip_atomic_store(addr, f32_bits(nq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return nq;
   }
   if (mode == kTdStoreNt) { __builtin_nontemporal_store(f32_bits(nq), addr); return nq; }
-  if (mode == kTdNone) return nq;
   if (mode == kTdAdd) { atomicAdd(&slot->q[a], nq - guess); return nq; }
+#endif
   for (int it = 0; it < max_cas; ++it) {
     const unsigned int prev = atomicCAS(addr, expect, f32_bits(nq));
     if (prev == expect) return nq;
-    ++retries;
+    ++ctrs.retries;
     expect = prev;
     nq = td_value(bits_f32(expect), reward, max_next, done, lr, gamma);
   }
-  // 16 lost races in a row: the entry is being rewritten every few hundred nanoseconds.  Spinning on
-  // costs far more than the sample is worth -- unbounded, a few such entries (the opening states
-  // at low epsilon) stretched every wave's step 4x (181 -> 71 us per 1 Mi boards at eps = 0.01,
-  // profiles/r02_strict_td_retries.jsonl) -- so the update is written as the default mode writes it
-  *addr = f32_bits(nq);
+  // kMaxCas lost races in a row: the entry is being rewritten every few hundred nanoseconds.
+  // Spinning on costs far more than exactness here is worth -- unbounded, a few such entries (the
+  // opening states at low epsilon) stretched every wave's step 4x (181 -> 71 us per 1 Mi boards at
+  // eps = 0.01, profiles/r02_strict_td_retries.jsonl) -- so the update goes in as an atomic add of
+  // its increment against the last value seen: nothing is lost, and the fall-back is counted
+  ++ctrs.fallbacks;
+  atomicAdd(&slot->q[a], nq - bits_f32(expect));
   return nq;
 }
 // Deferred TD writes: while a lane stays in one state (invalid moves: the board did not change)
@@ -351,7 +373,7 @@ __device__ __forceinline__ void flush_pending(q2048_slot* slot, const Row& q, ui
   pend = 0u;
 }
 __device__ __forceinline__ uint32_t td_mode_of(uint32_t flags) {
-  const uint32_t x = (flags >> 8) & 15u;  // experiment bits (not ABI)
+  const uint32_t x = Q2048_XBITS(flags, 8, 15u);  // measurement variants (experiment builds)
   return x ? x : ((flags & Q2048_FLAG_TD_CAS) ? kTdCas : kTdStorePlain);
 }
 
@@ -382,7 +404,7 @@ __device__ __forceinline__ void stats_flush(BlockStats& s, int64_t* gi, double* 
 }
 __device__ __forceinline__ void episode_stats(BlockStats& s, const Aux& a, uint32_t max_l2) {
   atomicAdd(&s.i[Q2048_ST_SCORE], (u64)(int64_t)a.score);
-  atomicAdd(&s.i[Q2048_ST_HIST0 + (max_l2 > 23u ? 23u : max_l2)], 1ull);
+  atomicAdd(&s.i[Q2048_ST_HIST0 + (max_l2 > 22u ? 22u : max_l2)], 1ull);
   const double ret = (double)a.ep_return;
   atomicAdd(&s.f[Q2048_SF_RETURN], ret);
   atomicAdd(&s.f[Q2048_SF_RETURN_SQ], ret * ret);
@@ -455,6 +477,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux*
   store_board(boards, i, B, b, st);
 }
 
+#ifdef Q2048_EXPERIMENTS
 // The 4x4 single-step kernel of the 4-call API for more than one board per thread (experiment
 // bits of q2048_env_step_ex): no LDS staging, and a thread requests board, aux and action of its
 // next board before it computes the current one.  Measured slower than one board per thread
@@ -498,10 +521,10 @@ __global__ __launch_bounds__(kBlock) void k_env_step4_pipelined(
     i = nxt; bv = bn; av = an; act = actn;
   }
 }
+#endif  // Q2048_EXPERIMENTS
 
-// The same step, one board per thread, without the loop: the setting that measures fastest, and
-// straight-line code spares the next-board addresses, the copies and the loop's branches (37
-// VGPRs instead of 70).  14.7 us per 1 Mi boards = 5.0 TB/s of the 70 B/step, 99.6 us per 8 Mi
+// The 4x4 step of the 4-call API: one board per thread in straight-line code (37 VGPRs, 8 waves
+// per SIMD; more boards per thread with register prefetch measured slower, profiles/r02_env_step.jsonl).  14.7 us per 1 Mi boards = 5.0 TB/s of the 70 B/step, 99.6 us per 8 Mi
 // boards = 5.9 TB/s (94 % of the 6.29 TB/s copy ceiling); a kernel that only moves the same bytes
 // takes 12.07 / 103.5 us (tools/exp_stream_floor.hip).
 template <int ENV>
@@ -637,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
   if (i < B) {
     const int act = actions[i];
     bool ins_n = false, ins_s = false, dropped = false;
-    uint32_t retries = 0;
+    TdCounters tdc{0u, 0u};
     if (act > 3) {
       atomicOr(status, Q2048_STATUS_BAD_ACTION);
     } else {
@@ -655,14 +678,15 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
       if (slot < 0 && slot != kNoSlot) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
       if (slot >= 0) {
         td_update(&table[slot], act, row_get(rs, act), reward[i], max_next, done[i] != 0, lr, gamma,
-                  retries, td_mode_of(flags));
+                  tdc, td_mode_of(flags));
       } else {
         dropped = true;
         atomicOr(status, Q2048_STATUS_TABLE_FULL);
       }
     }
     const uint32_t n_ins = wave_count(ins_n) + wave_count(ins_s), n_drop = wave_count(dropped);
-    if (retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)retries);
+    if (tdc.retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)tdc.retries);
+    if (tdc.fallbacks) atomicAdd(&bs.i[Q2048_ST_CAS_FALLBACK], (u64)tdc.fallbacks);
     if (wave_leader()) {
       if (n_ins) atomicAdd(&bs.i[Q2048_ST_INSERTS], (u64)n_ins);
       if (n_drop) atomicAdd(&bs.i[Q2048_ST_DROPS], (u64)n_drop);
@@ -687,7 +711,11 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
 #ifndef Q2048_FUSED_MIN_WAVES
 #define Q2048_FUSED_MIN_WAVES 6
 #endif
-template <int N, int ENV>
+// MODE: what the launch does with the table -- a template parameter, so the step loop carries no
+// run-time mode tests (kModeLearn: plain-store TD; kModeCas: Q2048_FLAG_TD_CAS; kModeEval:
+// Q2048_FLAG_NO_LEARN; play-only is an ENV bit).  Experiment builds select write modes at run time.
+constexpr int kModeLearn = 0, kModeCas = 1, kModeEval = 2;
+template <int N, int ENV, int MODE>
 __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
     double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
@@ -701,16 +729,24 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
   if (i < B) {
     const uint64_t id = env_id0 + (uint64_t)i;
     const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
-    const uint32_t td_mode = (flags & Q2048_FLAG_NO_LEARN) ? (uint32_t)kTdNone : td_mode_of(flags);
     // Q2048_FLAG_PLAY_ONLY (ENV bit kEnvPlayOnly: its own instantiation, so profiles tell the
     // learner-less launches from the learning ones): the table is never touched -- every row reads
-    // as zeros, nothing is created or written.  Experiment bits (not ABI): 12 no row creation,
-    // 13 no next-state probe
+    // as zeros, nothing is created or written.
+    // Q2048_FLAG_NO_LEARN (MODE kModeEval): evaluation of a trained table -- rows are read
+    // (epsilon-greedy over the stored values), nothing is created or written
     constexpr bool play_only = (ENV & kEnvPlayOnly) != 0;
-    // Q2048_FLAG_NO_LEARN: evaluation of a trained table -- rows are read (epsilon-greedy over the
-    // stored values), nothing is created or written
-    const bool no_learn = (flags & Q2048_FLAG_NO_LEARN) != 0;
+    constexpr bool no_learn = MODE == kModeEval;
+#ifdef Q2048_EXPERIMENTS   // bits 8..11 write mode, 12 no row creation, 13 no next-state probe, 14 no deferral, 16..23 CAS attempts
+    const uint32_t td_mode = no_learn ? (uint32_t)kTdNone : td_mode_of(flags);
     const bool x_noclaim = ((flags >> 12) & 1u) || play_only || no_learn, x_noprobe = ((flags >> 13) & 1u) || play_only;
+    const bool may_defer = td_mode == kTdStorePlain && !((flags >> 14) & 1u);
+    const int max_cas = ((flags >> 16) & 0xffu) ? (int)((flags >> 16) & 0xffu) : kMaxCas;
+#else
+    constexpr uint32_t td_mode = no_learn ? kTdNone : (MODE == kModeCas ? kTdCas : kTdStorePlain);
+    constexpr bool x_noclaim = play_only || no_learn, x_noprobe = play_only;
+    constexpr bool may_defer = td_mode == kTdStorePlain;
+    constexpr int max_cas = kMaxCas;
+#endif
     Aux a = ld_aux(aux, i);
     auto key_s = state_key(b, salt, status);
     Row q{0.f, 0.f, 0.f, 0.f};
@@ -719,10 +755,9 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
     Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
     uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = wave_count(made0), n_drop = 0;
-    uint32_t retries = 0, pend = 0;
+    uint32_t pend = 0;
+    TdCounters tdc{0u, 0u};
     double reward_sum = 0.0;
-    const bool may_defer = td_mode == kTdStorePlain && !((flags >> 14) & 1u);  // bit 14: experiment, off
-    const int max_cas = ((flags >> 16) & 0xffu) ? (int)((flags >> 16) & 0xffu) : kMaxCas;  // experiment
 
     for (int t = 0; t < steps; ++t) {
       const Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
@@ -754,7 +789,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
           pend |= 1u << act;
         } else {
           nq = td_update(&table[slot_s], act, row_get(q, act), o.reward, max_next, o.done != 0, lr,
-                         gamma, retries, td_mode, max_cas);
+                         gamma, tdc, td_mode, max_cas);
           pend &= ~(1u << act);
           if (pend) flush_pending(&table[slot_s], q, pend);
         }
@@ -809,7 +844,8 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
     st_aux(aux, i, a);
 
     if (n_drop) atomicOr(status, Q2048_STATUS_TABLE_FULL);
-    if (retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)retries);
+    if (tdc.retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)tdc.retries);
+    if (tdc.fallbacks) atomicAdd(&bs.i[Q2048_ST_CAS_FALLBACK], (u64)tdc.fallbacks);
     atomicAdd(&bs.f[Q2048_SF_REWARD], reward_sum);
     const uint32_t n_active = wave_count(true);
     if (wave_leader()) {
@@ -828,9 +864,18 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout
 // ---------------------------------------------------------------------------------------------
 // deterministic mode.  One step = phase 1 (every env acts on the table as it is at the start of
 // the step and emits where its update goes and its TD target), a stable radix sort of the updates
-// by the low bits of (row slot, action) -- two 8-bit passes of the radix partition below -- and
-// phase 2 (each (slot, action) group applies its updates in env order).  Nothing in it depends on how lanes are scheduled.
+// by a 16-bit hash of (state, action) -- two 8-bit passes of the radix partition below -- and
+// phase 2 (each (slot, action) group applies its updates in env order, one formula, one rounding).
+// The sort key is a function of the state and the action alone and the fold is the same sequence of
+// double operations on every path, so nothing in the result depends on how lanes are scheduled --
+// not even through which slot a racing insert happened to win.
+//
+// An update travels as one 64-bit word + its double target:
+//   bits 0..1 action | bits 2..43 row slot | bits 44..59 hash16(state, action) | 62 dropped | 63 applied
 // ---------------------------------------------------------------------------------------------
+constexpr int kDetHashShift = 44, kDetHashBits = 16;
+constexpr u64 kDetSlotMask = (1ull << kDetHashShift) - 1ull;
+constexpr u64 kDetDrop = 1ull << 62, kDetDone = 1ull << 63;
 constexpr uint32_t kNoCarry = 0xffffffffu;
 // the four values of a slot whose index is known: one 16-byte agent-scope request
 __device__ __forceinline__ Row ld_row(const q2048_slot* s) {
@@ -841,7 +886,7 @@ template <int N, int ENV>
 __global__ __launch_bounds__(kBlock) void k_det_phase1(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
     uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, double* target_out,
-    uint32_t* carry, int use_carry, int drop_bit, u64* longs, int64_t* stats_i, double* stats_f,
+    uint32_t* carry, int use_carry, u64* longs, int64_t* stats_i, double* stats_f,
     uint32_t* status) {
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
@@ -854,6 +899,7 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
     const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
     Aux a = ld_aux(aux, i);
     const auto key_s = state_key(b, salt, status);
+    const u64 hash_s = key_hash(key_s);
     const Draws x = draws(seed, id, ctr, kStreamStep);
     Draws y{0u, 0u, 0u, 0u};
     if constexpr ((ENV & kEnvDqn) != 0) y = draws(seed, id, ctr, kStreamOver);
@@ -879,11 +925,11 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
     int64_t slot_n = probe_find(table, mask, key_n, qn, ins_n);                         // :41
     if (slot_n < 0 && slot_n != kNoSlot) slot_n = probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
     carry[i] = (!o.done && slot_n >= 0 && (u64)slot_n < (u64)kNoCarry) ? (uint32_t)slot_n : kNoCarry;
-    // the group of this update: (slot of s, action); a dropped one sorts behind every group.  The
-    // sort is stable and this array is in env order, so env order survives without an index
-    group_out[i] = dropped ? (1ull << drop_bit) : (((u64)slot_s << 2) | (u64)act);
-    target_out[i] = (double)o.reward +
-                    (gamma * (double)max4(qn.q0, qn.q1, qn.q2, qn.q3) * (o.done ? 0.0 : 1.0));  // :42
+    // the group of this update: (slot of s, action), sorted by a hash of (s, action).  The sort is
+    // stable and this array is in env order, so env order survives without an index
+    const u64 h16 = ((hash_s >> 48) ^ ((u64)act * 0x5555ull)) & 0xffffull;
+    group_out[i] = dropped ? kDetDrop : ((h16 << kDetHashShift) | ((u64)slot_s << 2) | (u64)act);
+    target_out[i] = td_target(o.reward, max4(qn.q0, qn.q1, qn.q2, qn.q3), o.done != 0, gamma);   // :42
     if (o.done) {
       episode_stats(bs, a, o.max_log2);
       begin_episode(b, a, seed, id, (ENV & kEnvResetShaping) != 0);
@@ -1051,27 +1097,29 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const u64* kin, const u
   }
 }
 
-// Phase 2.  The updates arrive sorted -- stably, so env order survives -- by the LOW `sort_bits`
-// bits of group = (slot << 2) | action only: slots are hash values, so 16 bits (two radix passes
-// instead of five) already cut 2^20 updates into ~65 000 runs of ~16, and inside a run the
-// handful of distinct groups are told apart by comparing the full words.  Agent/main.py:43 is the
-// affine map q -> (1 - lr) q + lr * target; a group applies its maps in env order, in double
-// precision, and rounds to float32 once -- for one update that is exactly td_value().
+// Phase 2.  The updates arrive sorted -- stably, so env order survives -- by hash16(state, action)
+// only (two radix passes instead of six over the whole word): 2^20 updates fall into ~65 000 runs
+// of ~16, and inside a run the handful of distinct groups are told apart by comparing the full
+// words.  Agent/main.py:43 applied update by update in env order, in double precision, rounded to
+// float32 once per group and step -- td_fold(), the same operations in the same order on both paths
+// below (for a group of one that is exactly td_value()).
 //   k_det_apply       runs of up to kDetRun updates: the first update of every group in the run
 //                     folds the group's updates in env order and writes the cell (one lane per
 //                     update scans its run; ~700 000 independent read-modify-writes in flight).
 //                     Longer runs -- the states many envs share, e.g. right after a reset -- are
 //                     listed by their first update;
-//   k_det_apply_long  one wave per listed run: group after group, every lane composes the maps of
-//                     its contiguous share that belong to the group, the shares are composed in
-//                     order with a shuffle tree, lane 0 applies the result.
-// Which path a group takes and the shape of the tree depend on the sorted data only: the result
-// does not depend on scheduling.  kDetDone marks an update as applied (the sorted array is scratch).
+//   k_det_apply_long  one wave per listed run, one LANE per group: the wave walks the run 64
+//                     updates at a time, broadcasts each update in order, and the lane that owns its
+//                     group folds it in (up to 64 groups per sweep of the run; more take further
+//                     sweeps).
+// kDetDone marks an update as applied (the sorted array is scratch).
 constexpr int kDetRun = 64;
-constexpr u64 kDetDone = 1ull << 63;
+__device__ __forceinline__ float* det_cell(q2048_slot* table, u64 g) {
+  return &table[(g & kDetSlotMask) >> 2].q[g & 3ull];
+}
 __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u64* group,
                                                       const double* target, int64_t B, double lr,
-                                                      int drop_bit, u64 run_mask, u64* longs) {
+                                                      u64 run_mask, u64* longs) {
   // the block's 256 sorted words and kDetRun neighbours on either side, staged once: every
   // update scans its run (tens of words) and that traffic belongs in LDS, not in the L1
   __shared__ u64 tile[kBlock + 2 * kDetRun];
@@ -1099,19 +1147,23 @@ __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u
       longs[1ull + atomicAdd(&longs[0], 1ull)] = (u64)j;
     return;
   }
-  if (!first || (g >> drop_bit) != 0ull) return;                           // folded in by an earlier update / dropped
-  float* cell = &table[g >> 2].q[g & 3ull];
+  if (!first || (g & kDetDrop) != 0ull) return;                            // folded in by an earlier update / dropped
+  float* cell = det_cell(table, g);
   double q = (double)*cell;
   for (int k = 0; k <= fwd; ++k)
-    if (w[k] == g) q = q + lr * (target[j + k] - q);                       // Agent/main.py:43, env order
+    if (w[k] == g) q = td_fold(q, target[j + k], lr);                      // Agent/main.py:43, env order
   *cell = (float)q;
 }
 
+__device__ __forceinline__ u64 readlane64(u64 v, int lane) {
+  return (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane) |
+         ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32);
+}
 __global__ __launch_bounds__(kBlock) void k_det_apply_long(q2048_slot* table, u64* group,
                                                            const double* target, int64_t B, double lr,
-                                                           int drop_bit, u64 run_mask, const u64* longs) {
+                                                           u64 run_mask, const u64* longs) {
   const u64 n_long = longs[0];
-  const uint32_t lane = threadIdx.x & 63u;
+  const int lane = (int)(threadIdx.x & 63u);
   const u64 waves = (u64)gridDim.x * (kBlock / 64);
   for (u64 w = (u64)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n_long; w += waves) {
     const int64_t start = (int64_t)longs[1ull + w];
@@ -1123,32 +1175,49 @@ __global__ __launch_bounds__(kBlock) void k_det_apply_long(q2048_slot* table, u6
       if (same != ~0ull) { len += (int64_t)(__ffsll((long long)~same) - 1); break; }
       len += 64;
     }
-    const int64_t share = (len + 63) / 64;
-    const int64_t lo = start + (int64_t)lane * share;
-    const int64_t hi = lo + share < start + len ? lo + share : start + len;
-    int64_t cur = lo;                                    // first update of this share not yet applied
-    for (;;) {
-      while (cur < hi && (group[cur] >> drop_bit) != 0ull) ++cur;          // applied (bit 63) or dropped
-      const u64 have = __ballot(cur < hi);
-      if (have == 0ull) break;
-      const int first = __ffsll((long long)have) - 1;   // shares are in order: the run's first open update
-      const u64 g = __shfl(cur < hi ? group[cur] : 0ull, first);
-      double a = 1.0, b = 0.0;                           // identity for lanes without an update of g
-      for (int64_t k = cur; k < hi; ++k)
-        if (group[k] == g) {
-          a = a * (1.0 - lr);
-          b = b * (1.0 - lr) + lr * target[k];
-          group[k] = g | kDetDone;
+    for (;;) {                                           // one sweep: the first <= 64 open groups
+      // (a) which groups: in order of first appearance, lane k owns the k-th
+      u64 mine = 0ull;                                   // 0 is no group word (h16 | slot | action of a live update is never all zero: see below)
+      int n_owned = 0;
+      bool more = false;                                 // open groups beyond the 64 of this sweep
+      for (int64_t c = 0; c < len && !more; c += 64) {
+        const bool valid = c + lane < len;
+        const u64 g = valid ? group[start + c + lane] : kDetDone;
+        u64 open = __ballot((g & (kDetDone | kDetDrop)) == 0ull);
+        while (open != 0ull) {
+          const int k = __ffsll((long long)open) - 1;
+          open &= open - 1ull;
+          const u64 gk = readlane64(g, k) | kDetDone;    // tagged: never equals the "none" value 0
+          if (__ballot(mine == gk) != 0ull) continue;
+          if (n_owned == 64) { more = true; break; }
+          if (lane == n_owned) mine = gk;
+          ++n_owned;
         }
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {                 // (lane + d) after lane: a_hi (a q + b) + b_hi
-        const double a_hi = __shfl_down(a, d), b_hi = __shfl_down(b, d);
-        if ((lane & (2u * d - 1u)) == 0u) { b = a_hi * b + b_hi; a = a_hi * a; }
       }
-      if (lane == 0u) {
-        float* cell = &table[g >> 2].q[g & 3ull];
-        *cell = (float)(a * (double)*cell + b);
+      if (n_owned == 0) break;
+      // (b) every owner reads its cell (one round trip for the whole sweep), then (c) the run is
+      // walked again: each open update is broadcast in order and folded by its group's lane
+      float* cell = det_cell(table, mine);
+      double q = lane < n_owned ? (double)*cell : 0.0;
+      for (int64_t c = 0; c < len; c += 64) {
+        const bool valid = c + lane < len;
+        const u64 g = valid ? group[start + c + lane] : kDetDone;
+        const double t = valid ? target[start + c + lane] : 0.0;
+        u64 open = __ballot((g & (kDetDone | kDetDrop)) == 0ull);
+        bool taken = false;
+        while (open != 0ull) {
+          const int k = __ffsll((long long)open) - 1;
+          open &= open - 1ull;
+          const u64 gk = readlane64(g, k) | kDetDone;
+          const double tk = __longlong_as_double((long long)readlane64((u64)__double_as_longlong(t), k));
+          const bool own = mine == gk;
+          if (own) q = td_fold(q, tk, lr);               // Agent/main.py:43, env order
+          if (__ballot(own) != 0ull && lane == k) taken = true;
+        }
+        if (taken) group[start + c + lane] = g | kDetDone;
       }
+      if (lane < n_owned) *cell = (float)q;
+      if (!more) break;
     }
   }
 }
@@ -1455,21 +1524,49 @@ inline int check_table(const void* table, int cap_log2) {
     Q2048_LAUNCH_ENV_CASE(kernel, 2, n, B, stream, __VA_ARGS__)                                   \
     Q2048_LAUNCH_ENV_CASE(kernel, 3, n, B, stream, __VA_ARGS__)                                   \
   }
-// ... and with the play-only bit (the fused rollout)
-#define Q2048_LAUNCH_ENV8(kernel, flags, n, B, stream, ...)                                       \
-  switch (env_bits(flags)) {                                                                      \
-    Q2048_LAUNCH_ENV_CASE(kernel, 0, n, B, stream, __VA_ARGS__)                                   \
-    Q2048_LAUNCH_ENV_CASE(kernel, 1, n, B, stream, __VA_ARGS__)                                   \
-    Q2048_LAUNCH_ENV_CASE(kernel, 2, n, B, stream, __VA_ARGS__)                                   \
-    Q2048_LAUNCH_ENV_CASE(kernel, 3, n, B, stream, __VA_ARGS__)                                   \
-    Q2048_LAUNCH_ENV_CASE(kernel, 4, n, B, stream, __VA_ARGS__)                                   \
-    Q2048_LAUNCH_ENV_CASE(kernel, 5, n, B, stream, __VA_ARGS__)                                   \
-    Q2048_LAUNCH_ENV_CASE(kernel, 6, n, B, stream, __VA_ARGS__)                                   \
-    Q2048_LAUNCH_ENV_CASE(kernel, 7, n, B, stream, __VA_ARGS__)                                   \
+// the fused rollout: ENV with the play-only bit, MODE = what the launch does with the table
+#define Q2048_LAUNCH_FUSED_CASE(E, M, n, B, stream, ...)                                          \
+  case (E) * 4 + (M):                                                                             \
+    if ((n) == 4)                                                                                 \
+      hipLaunchKernelGGL((k_fused_rollout<4, E, M>), dim3(grid_for(B)), dim3(kBlock), 0,          \
+                         (hipStream_t)(stream), __VA_ARGS__);                                     \
+    else                                                                                          \
+      hipLaunchKernelGGL((k_fused_rollout<5, E, M>), dim3(grid_for(B)), dim3(kBlock), 0,          \
+                         (hipStream_t)(stream), __VA_ARGS__);                                     \
+    break;
+#define Q2048_LAUNCH_FUSED_ENV(E, n, B, stream, ...)                                              \
+  Q2048_LAUNCH_FUSED_CASE(E, kModeLearn, n, B, stream, __VA_ARGS__)                               \
+  Q2048_LAUNCH_FUSED_CASE(E, kModeCas, n, B, stream, __VA_ARGS__)                                 \
+  Q2048_LAUNCH_FUSED_CASE(E, kModeEval, n, B, stream, __VA_ARGS__)
+#define Q2048_LAUNCH_FUSED(flags, n, B, stream, ...)                                              \
+  switch (env_bits(flags) * 4 + fused_mode(flags)) {                                              \
+    Q2048_LAUNCH_FUSED_ENV(0, n, B, stream, __VA_ARGS__)                                          \
+    Q2048_LAUNCH_FUSED_ENV(1, n, B, stream, __VA_ARGS__)                                          \
+    Q2048_LAUNCH_FUSED_ENV(2, n, B, stream, __VA_ARGS__)                                          \
+    Q2048_LAUNCH_FUSED_ENV(3, n, B, stream, __VA_ARGS__)                                          \
+    Q2048_LAUNCH_FUSED_CASE(4, kModeLearn, n, B, stream, __VA_ARGS__)                             \
+    Q2048_LAUNCH_FUSED_CASE(5, kModeLearn, n, B, stream, __VA_ARGS__)                             \
+    Q2048_LAUNCH_FUSED_CASE(6, kModeLearn, n, B, stream, __VA_ARGS__)                             \
+    Q2048_LAUNCH_FUSED_CASE(7, kModeLearn, n, B, stream, __VA_ARGS__)                             \
   }
 inline int env_bits(uint32_t flags) {
   return ((flags & Q2048_FLAG_ENV_DQN) ? kEnvDqn : 0) | ((flags & Q2048_FLAG_RESET_SHAPING) ? kEnvResetShaping : 0) |
          ((flags & Q2048_FLAG_PLAY_ONLY) ? kEnvPlayOnly : 0);
+}
+inline int fused_mode(uint32_t flags) {   // play-only launches touch no table: one instantiation
+  if (flags & Q2048_FLAG_PLAY_ONLY) return kModeLearn;
+  return (flags & Q2048_FLAG_NO_LEARN) ? kModeEval : ((flags & Q2048_FLAG_TD_CAS) ? kModeCas : kModeLearn);
+}
+// flag bits outside the ABI are an argument error (experiment builds also take bits 8..23)
+constexpr uint32_t kAbiFlags = Q2048_FLAG_INDEPENDENT | Q2048_FLAG_SINGLE_ENV | Q2048_FLAG_TD_CAS |
+                               Q2048_FLAG_ENV_DQN | Q2048_FLAG_RESET_SHAPING | Q2048_FLAG_PLAY_ONLY |
+                               Q2048_FLAG_NO_LEARN;
+inline int check_flags(uint32_t flags, uint32_t refused = 0u) {
+  uint32_t allowed = kAbiFlags;
+#ifdef Q2048_EXPERIMENTS
+  allowed |= 0x00ffff00u;
+#endif
+  return ((flags & ~allowed) || (flags & refused)) ? Q2048_ERR_FLAGS : Q2048_OK;
 }
 }  // namespace
 
@@ -1496,6 +1593,7 @@ const char* q2048_strerror(int code) {
     case Q2048_ERR_UNSUPPORTED: return "unsupported board side (n must be 4 or 5)";
     case Q2048_ERR_LAUNCH: return "HIP launch failed";
     case Q2048_ERR_RANGE: return "scalar out of range (eps in [0,1], lr and gamma finite)";
+    case Q2048_ERR_FLAGS: return "flag bits this entry point does not take";
     default: return "unknown error";
   }
 }
@@ -1513,6 +1611,7 @@ int q2048_env_init(uint8_t* boards, q2048_aux* aux, int64_t B, int n, uint64_t s
 int q2048_env_reset_ex(uint8_t* boards, q2048_aux* aux, const uint8_t* mask, int64_t B, int n,
                        uint64_t seed, uint64_t env_id0, uint32_t flags, void* stream) {
   if (int e = check_batch(B, n)) return e;
+  if (int e = check_flags(flags)) return e;
   if (boards == nullptr || aux == nullptr) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
@@ -1532,31 +1631,31 @@ static int env_step_impl(uint8_t* boards, q2048_aux* aux, const uint8_t* actions
                          const uint32_t* draw_opos, const uint32_t* draw_oval, int draw_stride,
                          void* stream) {
   if (int e = check_batch(B, n)) return e;
+  if (int e = check_flags(flags)) return e;
   if (!boards || !aux || !actions || !reward || !done || !max_log2 || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
   if (B == 0) return Q2048_OK;
   if (n == 4 && draw_pos == nullptr) {
-    // Boards per thread: 1 measures fastest (15.0 us per 1 Mi boards against 15.4 / 16.3 / 19.6 for
-    // 2 / 4 / 8: at 8 waves per SIMD the hardware already overlaps one wave's loads with another's
-    // arithmetic, and a longer thread only delays its own stores); experiment bits 8..11 override
+    unsigned blocks = grid_for(B);
+#ifdef Q2048_EXPERIMENTS   // bits 8..11: boards per thread (k_env_step4_pipelined)
     const int64_t per_thread = ((flags >> 8) & 15u) ? (int64_t)((flags >> 8) & 15u) : 1;
-    int64_t blocks = (B + kBlock * per_thread - 1) / (kBlock * per_thread);
-    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
-    if (per_thread == 1) {
+    if (per_thread > 1) {
+      blocks = (unsigned)((B + kBlock * per_thread - 1) / (kBlock * per_thread));
       if (flags & Q2048_FLAG_ENV_DQN)
-        hipLaunchKernelGGL(k_env_step4<kEnvDqn>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(k_env_step4_pipelined<kEnvDqn>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
                            boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status);
       else
-        hipLaunchKernelGGL(k_env_step4<0>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(k_env_step4_pipelined<0>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
                            boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status);
-    } else if (flags & Q2048_FLAG_ENV_DQN)
-      hipLaunchKernelGGL(k_env_step4_pipelined<kEnvDqn>, dim3((unsigned)blocks), dim3(kBlock), 0,
-                         (hipStream_t)stream, boards, aux, actions, B, seed, env_id0, ctr, reward, done,
-                         max_log2, status);
+      return launch_status();
+    }
+#endif
+    if (flags & Q2048_FLAG_ENV_DQN)
+      hipLaunchKernelGGL(k_env_step4<kEnvDqn>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                         boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status);
     else
-      hipLaunchKernelGGL(k_env_step4_pipelined<0>, dim3((unsigned)blocks), dim3(kBlock), 0,
-                         (hipStream_t)stream, boards, aux, actions, B, seed, env_id0, ctr, reward, done,
-                         max_log2, status);
+      hipLaunchKernelGGL(k_env_step4<0>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                         boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status);
     return launch_status();
   }
   Q2048_LAUNCH_ENV(k_env_step, flags & Q2048_FLAG_ENV_DQN, n, B, stream, boards, aux, actions, B, seed,
@@ -1597,6 +1696,7 @@ static int q_choose_impl(const q2048_slot* table, int cap_log2, const uint8_t* b
                          uint32_t flags, uint8_t* actions, uint32_t* status,
                          const uint32_t* draw_eps, const uint32_t* draw_act, void* stream) {
   if (int e = check_batch(B, n)) return e;
+  if (int e = check_flags(flags)) return e;
   if (int e = check_table(table, cap_log2)) return e;
   if (!boards || !actions || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards)) return Q2048_ERR_ALIGN;
@@ -1628,6 +1728,7 @@ int q2048_q_update(q2048_slot* table, int cap_log2, const uint8_t* boards_s, con
                    int n, double lr, double gamma, uint64_t env_id0, uint32_t flags,
                    int64_t* stats_i, uint32_t* status, void* stream) {
   if (int e = check_batch(B, n)) return e;
+  if (int e = check_flags(flags)) return e;
   if (int e = check_table(table, cap_log2)) return e;
   if (!boards_s || !actions || !reward || !boards_s2 || !done || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards_s) || !aligned16(boards_s2)) return Q2048_ERR_ALIGN;
@@ -1642,6 +1743,7 @@ int q2048_q_lookup(const q2048_slot* table, int cap_log2, const uint8_t* boards,
                    uint64_t env_id0, uint32_t flags, float* q_out, uint8_t* found, uint32_t* status,
                    void* stream) {
   if (int e = check_batch(B, n)) return e;
+  if (int e = check_flags(flags)) return e;
   if (int e = check_table(table, cap_log2)) return e;
   if (!boards || !q_out || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(q_out)) return Q2048_ERR_ALIGN;
@@ -1666,6 +1768,7 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
                             int64_t* stats_i, double* stats_f, uint32_t* status, q2048_episode* log,
                             int64_t log_capacity, uint64_t* log_count, void* stream) {
   if (int e = check_batch(B, n)) return e;
+  if (int e = check_flags(flags)) return e;
   if (log != nullptr && (log_count == nullptr || log_capacity < 0)) return Q2048_ERR_NULL;
   if (log != nullptr && !aligned16(log)) return Q2048_ERR_ALIGN;
   if (int e = check_table(table, cap_log2)) return e;
@@ -1674,9 +1777,9 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
   if (steps < 0 || steps > (1 << 30)) return Q2048_ERR_SIZE;
   if (!(eps >= 0.0 && eps <= 1.0) || !(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
   if (B == 0 || steps == 0) return Q2048_OK;
-  Q2048_LAUNCH_ENV8(k_fused_rollout, flags, n, B, stream, boards, aux, table,
-                   (u64)((1ull << cap_log2) - 1ull), B, (int)steps, eps, lr, gamma, seed, env_id0, ctr0,
-                   flags, stats_i, stats_f, status, log, log_capacity, reinterpret_cast<u64*>(log_count));
+  Q2048_LAUNCH_FUSED(flags, n, B, stream, boards, aux, table,
+                     (u64)((1ull << cap_log2) - 1ull), B, (int)steps, eps, lr, gamma, seed, env_id0, ctr0,
+                     flags, stats_i, stats_f, status, log, log_capacity, reinterpret_cast<u64*>(log_count));
   return launch_status();
 }
 
@@ -1711,8 +1814,11 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
                       double* stats_f, uint32_t* status, void* workspace, int64_t workspace_bytes,
                       void* stream) {
   if (int e = check_batch(B, n)) return e;
+  // no learner-less or evaluation form of the deterministic step: refuse rather than learn anyway
+  if (int e = check_flags(flags, Q2048_FLAG_NO_LEARN | Q2048_FLAG_PLAY_ONLY)) return e;
   if (B > 0x7fffffffll) return Q2048_ERR_SIZE;                       // one sort of at most 2^31 updates
   if (int e = check_table(table, cap_log2)) return e;
+  static_assert(40 + 2 <= kDetHashShift, "slot << 2 | action fits below the hash field");
   if (!boards || !aux || !status || !workspace) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux) || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return Q2048_ERR_ALIGN;
   if (steps < 0 || steps > (1 << 30)) return Q2048_ERR_SIZE;
@@ -1730,20 +1836,21 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   u64* longs = reinterpret_cast<u64*>(ws + L.longs);
   const hipStream_t s = (hipStream_t)stream;
   const u64 mask = (1ull << cap_log2) - 1ull;
-  const int drop_bit = cap_log2 + 2;
-  // sort width: the low 16 bits tell runs apart (comment at k_det_apply); experiment bits 8..13 of
-  // flags override it (the tests sort by 3 and by 8 bits to force crowded runs, and by all bits)
-  const int full_bits = drop_bit + 1;
-  int sort_bits = (int)((flags >> 8) & 63u) ? (int)((flags >> 8) & 63u) : 16;
-  if (sort_bits > full_bits) sort_bits = full_bits;
-  const u64 run_mask = (1ull << sort_bits) - 1ull;
+  // sort range: the 16 hash bits of the update word (comment at k_det_apply).  Experiment builds:
+  // bits 8..13 of flags = k sorts by the low k hash bits only (crowded runs), 63 by the whole word
+  int sort_lo = kDetHashShift, sort_hi = kDetHashShift + kDetHashBits;
+  if (const int xb = (int)Q2048_XBITS(flags, 8, 63u)) {
+    if (xb < kDetHashBits) sort_hi = sort_lo + xb;
+    else if (xb == 63) sort_lo = 0;
+  }
+  const u64 run_mask = ((1ull << sort_hi) - 1ull) & ~((1ull << sort_lo) - 1ull);
   for (int64_t t = 0; t < steps; ++t) {
     Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
-                     ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), drop_bit, longs,
+                     ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), longs,
                      stats_i, stats_f, status);
     int cur = 0;                                     // which buffer holds the pairs
-    for (int lo = 0; lo < sort_bits; lo += 8, cur ^= 1) {
-      const uint32_t dmask = sort_bits - lo >= 8 ? 255u : (1u << (sort_bits - lo)) - 1u;
+    for (int lo = sort_lo; lo < sort_hi; lo += 8, cur ^= 1) {
+      const uint32_t dmask = sort_hi - lo >= 8 ? 255u : (1u << (sort_hi - lo)) - 1u;
       hipLaunchKernelGGL(k_sort_count, dim3((unsigned)L.tiles), dim3(kBlock), 0, s, group[cur], B, lo, dmask,
                          cnt, L.tiles);
       hipLaunchKernelGGL(k_sort_scan, dim3(kBlock), dim3(kBlock), 0, s, cnt, L.tiles, total_cnt);
@@ -1752,9 +1859,9 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
                          reinterpret_cast<u64*>(target[cur ^ 1]), B, lo, dmask, cnt, total_cnt, L.tiles);
     }
     hipLaunchKernelGGL(k_det_apply, dim3(grid_for(B)), dim3(kBlock), 0, s, table, group[cur], target[cur], B, lr,
-                       drop_bit, run_mask, longs);
+                       run_mask, longs);
     hipLaunchKernelGGL(k_det_apply_long, dim3(256), dim3(kBlock), 0, s, table, group[cur], target[cur], B, lr,
-                       drop_bit, run_mask, longs);
+                       run_mask, longs);
     if (int e = launch_status()) return e;
   }
   return Q2048_OK;

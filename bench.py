@@ -271,6 +271,8 @@ def run_rank(args):
     import torch
 
     pkg = importlib.import_module("2048_q-learning_amd")
+    if args.experiment_bits:          # ablation bits exist in the measurement build only
+        pkg._native.use_experiments_build()
     rank, local_rank, world = pkg.dist.init_process_group()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

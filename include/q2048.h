@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define Q2048_ABI_VERSION 2 /* 2: env profiles (_ex entry points), PLAY_ONLY, device-side deterministic step */
+#define Q2048_ABI_VERSION 3 /* 3: flag bits outside the ABI are refused (Q2048_ERR_FLAGS), Q2048_ST_CAS_FALLBACK,
+                               deterministic step sorted by a hash of (state, action) */
 
 /* return codes */
 #define Q2048_OK 0
@@ -50,6 +51,7 @@ extern "C" {
 #define Q2048_ERR_UNSUPPORTED (-4) /* board side other than 4 or 5 */
 #define Q2048_ERR_LAUNCH (-5)      /* the HIP runtime refused the launch */
 #define Q2048_ERR_RANGE (-6)       /* a scalar is outside its domain (eps, lr, gamma) */
+#define Q2048_ERR_FLAGS (-7)       /* flag bits outside the ABI, or flags the entry point refuses */
 
 /* bits of the device status word */
 #define Q2048_STATUS_BAD_ACTION 1u    /* an action outside 0..3 was passed (lane left untouched) */
@@ -60,10 +62,12 @@ extern "C" {
 #define Q2048_FLAG_INDEPENDENT 1u /* every env owns private Q rows (key salted by its global id) */
 #define Q2048_FLAG_SINGLE_ENV 2u  /* q_lookup: every board belongs to env `env_id0` (not env_id0 + i) */
 #define Q2048_FLAG_TD_CAS 4u      /* TD update by a compare-and-swap loop: concurrent updates of one
-                                     (s, a) serialise instead of "last writer wins" (for up to 16
+                                     (s, a) serialise instead of "last writer wins" -- for up to 16
                                      attempts per update; an entry contended beyond that takes the
-                                     update as a plain store); identical to the default whenever
-                                     no two lanes share (s, a) */
+                                     update as an atomic add of its increment (nothing is lost, the
+                                     weight is taken against a slightly stale value) and the event
+                                     is counted in Q2048_ST_CAS_FALLBACK.  Identical to the default
+                                     whenever no two lanes share (s, a) */
 
 #define Q2048_FLAG_ENV_DQN 8u      /* env step = the DQN path's env instead of Game2048_env.step:
                                      Deep_QLearning/environment/Game2048_nopenalty_env.py:106-138 --
@@ -134,7 +138,9 @@ enum {
   Q2048_ST_DROPS = 5,    /* updates dropped (probe limit) */
   Q2048_ST_EXPLORE = 6,  /* epsilon branch taken */
   Q2048_ST_CAS_RETRY = 7,/* TD compare-and-swap retries (same (s,a) updated concurrently) */
-  Q2048_ST_HIST0 = 8,    /* max-tile histogram of finished episodes, log2 0..23 */
+  Q2048_ST_HIST0 = 8,    /* max-tile histogram of finished episodes, log2 0..22 (saturating) */
+  Q2048_ST_CAS_FALLBACK = 31, /* Q2048_FLAG_TD_CAS updates that lost 16 races in a row and went in
+                                 as an atomic add of their increment instead */
   Q2048_NSTAT_I = 32
 };
 enum { Q2048_SF_RETURN = 0, Q2048_SF_RETURN_SQ = 1, Q2048_SF_REWARD = 2, Q2048_NSTAT_F = 4 };
@@ -230,7 +236,8 @@ int q2048_q_lookup(const q2048_slot *table, int cap_log2, const uint8_t *boards,
  * aux and the Q row of the current state stay in registers between steps.  Step t uses the
  * draws of counter ctr0 + t.  Bit-identical to calling q_choose / env_step / q_update /
  * env_reset(done) `steps` times whenever no two lanes share a state.
- * flags: Q2048_FLAG_INDEPENDENT, _TD_CAS, _ENV_DQN, _RESET_SHAPING, _PLAY_ONLY, _NO_LEARN. */
+ * flags: Q2048_FLAG_INDEPENDENT, _TD_CAS, _ENV_DQN, _RESET_SHAPING, _PLAY_ONLY, _NO_LEARN; any bit
+ * outside the Q2048_FLAG_* set is Q2048_ERR_FLAGS (all entry points). */
 int q2048_fused_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2,
                         int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
                         uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
@@ -253,14 +260,18 @@ int q2048_fused_rollout_log(uint8_t *boards, q2048_aux *aux, q2048_slot *table, 
  *            START of the step (phase 1 writes no Q value; it creates the rows of s and s' like
  *            update_q_value does, Agent/main.py:41-43) and emits its update: (row slot, action)
  *            and the TD target reward + gamma * max Q(s') * (1 - done) (:42);
- *   sort     the updates are sorted on the device, stably, by the low 16 bits of (slot, action):
+ *   sort     the updates are sorted on the device, stably, by a 16-bit hash of (state, action):
  *            the updates of a group end up in one short run, in env order;
- *   phase 2  every group applies Q[s][a] += lr * (target - Q[s][a]) (:43) in env order (double
- *            precision inside a group, one rounding to float32; for a group of one that is the
- *            reference update exactly).
+ *   phase 2  every group applies Q[s][a] += lr * (target - Q[s][a]) (:43) update by update in env
+ *            order, in the reference's double arithmetic (no fused multiply-add), and rounds to
+ *            float32 once per group and step.
  * The result equals the reference agent fed the step's transitions in env order against the
- * step-start table, for any B, bit-identically from run to run.  `steps` steps per call, draws of
- * counter ctr0 + t; flags as q2048_fused_rollout (TD_CAS / PLAY_ONLY have no meaning here).
+ * step-start table with its rows held as float32, for any B, and is a function of the inputs
+ * alone: the sort key depends on the state and the action, never on which slot a racing insert
+ * won, and every group is folded by the same sequence of operations whatever its size.  `steps`
+ * steps per call, draws of counter ctr0 + t.  flags: Q2048_FLAG_INDEPENDENT, _ENV_DQN,
+ * _RESET_SHAPING; _TD_CAS is ignored; _NO_LEARN and _PLAY_ONLY are refused (Q2048_ERR_FLAGS: there
+ * is no evaluation form of this step, and learning anyway would be the wrong answer).
  * `workspace`: caller-owned device scratch of q2048_det_workspace_bytes(B, cap_log2) bytes
  * (about 36 bytes per env; host arithmetic, needs no device), 256-byte aligned (B < 2^31).  It
  * holds no state between calls. */

@@ -100,6 +100,7 @@ def lib() -> C.CDLL:
         "orc_agent_decay": (None, [vp, C.c_double]),
         "orc_agent_q": (C.c_int, [vp, u8p, f64p]),
         "orc_agent_size": (C.c_int64, [vp]),
+        "orc_agent_set_storage_f32": (None, [vp, C.c_int]),
         "orc_agent_dump": (C.c_int64, [vp, u8p, f64p, C.c_int64]),
         "orc_envs_init": (None, [vp, C.c_int64, C.c_int, C.c_uint64, C.c_uint64]),
         "orc_rollout": (None, [vp, C.c_int64, vp, C.c_int64, C.c_uint64, C.c_uint64,
@@ -262,10 +263,14 @@ class Env:
 # ---- agent --------------------------------------------------------------------------
 class Agent:
     def __init__(self, total_epochs, action_space=4, learning_rate=0.1, discount_factor=0.9,
-                 exploration_rate=1.0, exploration_min=0.01, n: int = 4):
+                 exploration_rate=1.0, exploration_min=0.01, n: int = 4, storage_f32: bool = False):
+        """storage_f32: rows hold float32 values (the device's storage type; a documented deviation
+        from the reference's float64 dict, see orc_agent_t.storage_f32)."""
         self.n = n
         self._h = lib().orc_agent_new(float(total_epochs), action_space, learning_rate,
                                       discount_factor, exploration_rate, exploration_min, n)
+        if storage_f32:
+            lib().orc_agent_set_storage_f32(self._h, 1)
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:  # _lib is gone at interpreter exit
@@ -370,10 +375,12 @@ def rollout_sync(envs: np.ndarray, agent: Agent, steps: int, seed: int = 0, env_
     return si, sf
 
 
-def rollout_mt(envs: np.ndarray, agents: list[Agent], steps: int, seed: int = 0,
-               env_id0: int = 0, ctr0: int = 0):
-    T = len(agents)
-    hs = (C.c_void_p * T)(*[a._h for a in agents])
+def rollout_mt(envs: np.ndarray, agents: "list[Agent] | None", steps: int, seed: int = 0,
+               env_id0: int = 0, ctr0: int = 0, threads: int = 0):
+    """T threads over contiguous env ranges: one private learner each (`agents`), or, with
+    agents=None, `threads` threads of uniformly random play (no learner)."""
+    T = len(agents) if agents is not None else int(threads)
+    hs = (C.c_void_p * T)(*[a._h for a in agents]) if agents is not None else None
     si = np.zeros(ST_NI, dtype=np.int64)
     sf = np.zeros(SF_NF, dtype=np.float64)
     lib().orc_rollout_mt(envs.ctypes.data, len(envs), hs, T, steps, seed, env_id0,

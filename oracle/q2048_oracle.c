@@ -462,6 +462,7 @@ void orc_agent_update(orc_agent_t *a, const uint8_t *s, int action, double rewar
   double target = reward + (a->gamma * qn * (double)(1 - (done ? 1 : 0))); /* :42 */
   orc_row_t *rs = orc_qtable_get(a->q, k1, NULL); /* may grow: rn is dead from here */
   rs->q[action] += a->lr * (target - rs->q[action]);                       /* :43 */
+  if (a->storage_f32) rs->q[action] = (double)(float)rs->q[action];        /* float32 table (option) */
 }
 
 /* QLearningAgent.decay_exploration (:45-57) */
@@ -485,6 +486,7 @@ int orc_agent_q(const orc_agent_t *a, const uint8_t *board, double out[4]) {
 }
 
 int64_t orc_agent_size(const orc_agent_t *a) { return a->q->size; }
+void orc_agent_set_storage_f32(orc_agent_t *a, int on) { a->storage_f32 = on ? 1 : 0; }
 
 int64_t orc_agent_dump(const orc_agent_t *a, uint8_t *keys, double *vals, int64_t max_rows) {
   int64_t w = 0;
@@ -530,7 +532,8 @@ void orc_rollout_ex(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t step
       memcpy(s, e->board, ORC_MAXCELLS);
       int explored = 0, a;
       if (agent) a = orc_agent_choose(agent, s, x[0], x[1], &explored);   /* main.py:92 */
-      else a = actions[t * B + i];
+      else if (actions) a = actions[t * B + i];
+      else { a = orc_draw_action(x[1]); explored = 1; }                   /* random play */
       double r; int done, mx;
       int64_t size0 = agent ? agent->q->size : 0;
       int valid;
@@ -541,6 +544,7 @@ void orc_rollout_ex(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t step
       } else {
         valid = orc_env_step(e, a, x[2], x[3], &r, &done, &mx);            /* :93 */
       }
+      if (agent && agent->storage_f32) r = (double)(float)r; /* the device hands rewards over as float32 */
       if (agent) orc_agent_update(agent, s, a, r, e->board, done);         /* :99 */
       e->episode_return += r;                                              /* :101 */
       if (out_actions) out_actions[t * B + i] = (uint8_t)a;
@@ -624,6 +628,13 @@ void orc_rollout_sync(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t st
       orc_row_t *rs = orc_qtable_get(agent->q, k1, NULL);
       rs->q[act[i]] += agent->lr * (target[i] - rs->q[act[i]]);               /* :43 */
     }
+    if (agent->storage_f32)                                /* one rounding per touched entry and step */
+      for (int64_t i = 0; i < B; ++i) {
+        uint8_t k1[ORC_MAXCELLS];
+        orc_key_of(agent, s_all + i * ORC_MAXCELLS, k1);
+        orc_row_t *rs = orc_qtable_find(agent->q, k1);
+        rs->q[act[i]] = (double)(float)rs->q[act[i]];
+      }
   }
   free(s_all); free(act); free(target);
 }
@@ -648,7 +659,7 @@ void orc_rollout_mt(orc_env_t *envs, int64_t B, orc_agent_t **agents, int T, int
   pthread_t *th = (pthread_t *)calloc((size_t)T, sizeof *th);
   for (int k = 0; k < T; ++k) {
     int64_t lo = B * k / T, hi = B * (k + 1) / T;
-    jobs[k].envs = envs + lo; jobs[k].B = hi - lo; jobs[k].agent = agents[k];
+    jobs[k].envs = envs + lo; jobs[k].B = hi - lo; jobs[k].agent = agents ? agents[k] : NULL;
     jobs[k].steps = steps; jobs[k].seed = seed; jobs[k].env_id0 = env_id0 + (uint64_t)lo;
     jobs[k].ctr0 = ctr0;
     pthread_create(&th[k], NULL, orc_job_run, &jobs[k]);

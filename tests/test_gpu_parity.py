@@ -228,6 +228,38 @@ def test_abi_argument_errors(pkg):
         pkg.BatchedGame2048Env(4, profile="other", device=DEV)
 
 
+def test_flag_bits_outside_the_abi_are_refused(pkg):
+    """The shipped library takes the Q2048_FLAG_* bits of include/q2048.h and nothing else (the
+    ablation / sort-width / write-mode bits exist only in the measurement build): any other bit is
+    Q2048_ERR_FLAGS, nothing is launched.  The deterministic step has no evaluation or learner-less
+    form and refuses NO_LEARN / PLAY_ONLY instead of learning anyway."""
+    N = pkg._native
+    env = pkg.BatchedGame2048Env(64, seed=1, device=DEV)
+    agent = pkg.BatchedQLearningAgent(10, capacity_log2=12, seed=1, device=DEV)
+    before = env.boards.clone()
+    for bits in (1 << 8, 1 << 12, 1 << 14, 5 << 16, 1 << 7, 1 << 31):
+        agent.experiment_bits = bits
+        with pytest.raises(N.NativeError, match="flag bits"):
+            agent.fused_rollout(env, 3)
+        with pytest.raises(N.NativeError, match="flag bits"):
+            agent.deterministic_rollout(env, 1)
+    agent.experiment_bits = 0
+    for refused in (N.FLAG_NO_LEARN, N.FLAG_PLAY_ONLY):
+        agent.flags = refused
+        with pytest.raises(N.NativeError, match="flag bits"):
+            agent.deterministic_rollout(env, 1)
+    agent.flags = 0
+    a = torch.zeros(64, dtype=torch.uint8, device=DEV)
+    assert N.lib().q2048_q_choose(agent.table.data_ptr(), 12, env.boards.data_ptr(), 64, 4, 0.5, 1, 0, 0, 1 << 9,
+                                  a.data_ptr(), agent.status.data_ptr(), None) == -7
+    assert torch.equal(env.boards, before) and agent.table_size() == 0 and env.ctr == 0 == agent.ctr
+    # ... and the measurement build of the same sources takes them
+    X = N.load(N.build_experiments())
+    assert X.q2048_q_choose(agent.table.data_ptr(), 12, env.boards.data_ptr(), 64, 4, 0.5, 1, 0, 0, 1 << 9,
+                            a.data_ptr(), agent.status.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+
+
 # ---------------------------------------------------------------------------------------------
 # env profiles: the DQN path's env (Game2048_nopenalty_env.py) and the shaping-state reset
 # ---------------------------------------------------------------------------------------------
@@ -1302,22 +1334,21 @@ def test_c_host_program_drives_the_abi(pkg, tmp_path):
 @pytest.mark.parametrize("n,B,steps,sort_bits", [(4, 3000, 80, 0), (5, 1500, 60, 0), (4, 60000, 24, 0),
                                                   (4, 3000, 80, 3), (5, 1500, 60, 8), (4, 60000, 24, 63),
                                                   (4, 60000, 24, 10), (4, 2500, 330, 0), (5, 2100, 300, 0)])
-def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, n, B, steps, sort_bits):
+def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, monkeypatch, n, B, steps, sort_bits):
     """Shared table, lanes meeting on common states, epsilon < 1 (actions depend on Q): the
-    deterministic mode equals the oracle's two-phase semantic -- boards bit-exact, the WHOLE
-    Q-table within tolerance -- and two runs give bit-identical tables.  `sort_bits` (experiment
-    bits of the flags; 0 = the default 16) sets how many bits of (row, action) the updates are
-    sorted by: 3 and 8 make every run of the sorted array a crowd of different groups (each told
-    apart by the full word), 63 sorts by everything (a run is a group), 10 mixes long runs with
-    crowded ones.
-    (Not run at 1,048,576 boards: from reset, thousands of lanes sit on symmetric opening states whose
-    two mirror actions hold values that are equal in the device's float32 table and 2e-14 apart in
-    the oracle's float64 one -- 2.867381811141947 vs ...966 measured -- so the two argmaxes pick
-    different, equally good, actions and the trajectories part at step 1.  That is the float32
-    table of the north star meeting a float64 reference, not an ordering effect; with private rows
-    `test_full_size_1m_lanes_q_dependent_actions` checks 1 Mi lanes at eps = 0.2.)"""
+    deterministic mode equals the oracle's two-phase semantic with float32 rows (the oracle's
+    `storage_f32` option, pinned against G6/G7) -- boards bit-exact and the WHOLE Q-table BIT-EXACT:
+    both sides fold a group's updates in env order with the same double operations (no fused
+    multiply-add) and round to float32 once per group and step -- and two runs give bit-identical
+    tables.  `sort_bits` != 0 runs on the measurement build (tools/variants/libq2048_hip_exp.so, the
+    same sources with -DQ2048_EXPERIMENTS): the updates are then sorted by the low 3 / 8 / 10 bits
+    of the 16-bit (state, action) hash, which makes every run of the sorted array a crowd of
+    different groups (each told apart by the full word) or mixes long runs with crowded ones, or by
+    the whole word (63: a run is a group)."""
     seed, id0, eps, lr, gamma = 41, 10, 0.2, 0.1, 0.95
     cells = n * n
+    if sort_bits:
+        monkeypatch.setattr(pkg._native, "_lib", pkg._native.load(pkg._native.build_experiments()))
 
     def run():
         env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
@@ -1333,13 +1364,14 @@ def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, n, B, steps
     if B >= 60000:      # many envs on the few opening states: groups longer than one lane walks alone
         _, first = np.unique(envs["board"][:, :cells], axis=0, return_counts=True)
         assert first.max() > 200
-    oa = O.Agent(100, 4, lr, gamma, eps, n=n)
+    oa = O.Agent(100, 4, lr, gamma, eps, n=n, storage_f32=True)
     si, sf = O.rollout_sync(envs, oa, steps, seed, id0, 0)
     assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :cells])
     assert_aux(env.aux_fields(), envs, "deterministic")
     keys, vals = oa.dump()
     got = agent.q_values(t8(keys)).cpu().numpy()
     assert np.allclose(got, vals, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(got, vals.astype(np.float32)), f"{(got != vals.astype(np.float32)).sum()} entries differ in the last bit"
     shared = int((np.abs(vals) > 0).sum(axis=1).max())
     st = agent.stats()
     assert st["steps"] == B * steps and st["episodes"] == si[O.ST_EPISODES] and st["explored"] == si[O.ST_EXPLORE]
@@ -1354,6 +1386,65 @@ def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, n, B, steps
     o1 = np.lexsort(k1.T[::-1]); o2 = np.lexsort(k2.T[::-1])
     assert np.array_equal(k1[o1], k2[o2]) and np.array_equal(q1[o1], q2[o2])      # bit-identical
     assert agent.check_status() == 0
+
+
+@pytest.mark.parametrize("eps", [1.0, 0.95, 0.2])
+def test_deterministic_mode_1m_boards_matches_oracle(pkg, O, eps):
+    """The bench's own size on ONE shared table against the sequential semantic
+    (Agent/main.py:34-43 fed in env order): 1 048 576 boards, 2^30 slots, 8 deterministic steps from
+    reset (thousands of lanes per opening state: long runs, one wave each), 256 steps of random play
+    with no learner (the bench's input synthesis), 8 more steps on mid-game boards (about 16 distinct
+    groups per sorted run).  512 sort tiles: `k_sort_scan` walks its rows in two chunks.
+      eps = 1     against the unmodified float64 oracle: actions come from draws alone, so the
+                  trajectories are exact whatever the table holds; whole table within 1e-5.
+      eps < 1     actions depend on argmax over rows that thousands of lanes share.  The float64
+                  oracle breaks mirror-state ties differently from a float32 table (values 2e-14
+                  apart in float64 are equal in float32), so the checker is the oracle with float32
+                  rows (`storage_f32`, pinned against G6/G7): boards bit-exact, table BIT-EXACT.
+    inserts == len(q_table) == the oracle's dict size in every case."""
+    B, seed, id0, lr, gamma, cap = 1 << 20, 17, 3, 0.1, 0.99, 30
+    release_cached_device_memory()
+    env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                      capacity_log2=cap, seed=seed, env_id0=id0, device=DEV, placement="plain")
+    envs = O.envs_init(B, 4, seed, id0)
+    oa = O.Agent(100, 4, lr, gamma, eps, storage_f32=eps < 1.0)
+    oa.reserve(14 << 20)
+    threads = max(1, min(64, (os.cpu_count() or 8)))
+
+    def check(what):
+        assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16]), what
+        assert_aux(env.aux_fields(), envs, what)
+        keys, vals = oa.dump()
+        got = agent.q_values(t8(keys)).cpu().numpy()
+        assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), what
+        if eps < 1.0:
+            ne = int((got != vals.astype(np.float32)).sum())
+            assert ne == 0, f"{what}: {ne} of {got.size} Q entries differ in the last bit"
+        st = agent.stats()
+        assert st["inserts"] == agent.table_size() == len(oa) and st["drops"] == 0, what
+        return st, vals
+
+    agent.deterministic_rollout(env, 8)
+    si, _ = O.rollout_sync(envs, oa, 8, seed, id0, 0)
+    st, vals = check("from reset")
+    _, first = np.unique(O.envs_init(B, 4, seed, id0)["board"][:, :16], axis=0, return_counts=True)
+    assert first.max() > 64 * 16                      # opening states shared by thousands of lanes
+    assert st["steps"] == 8 * B and st["explored"] == si[O.ST_EXPLORE]
+    # input synthesis as bench.py does it: random play, no learner, the table untouched
+    agent.epsilon = 1.0
+    agent.fused_rollout(env, 256, play_only=True)
+    agent.epsilon = eps
+    O.rollout_mt(envs, None, 256, seed, id0, 8, threads=threads)
+    rows_before = len(oa)
+    assert agent.table_size() == rows_before
+    agent.deterministic_rollout(env, 8)
+    si2, _ = O.rollout_sync(envs, oa, 8, seed, id0, 264)
+    st, vals = check("mid-game")
+    assert st["episodes"] > 1000 and len(oa) - rows_before > 4 * B     # mid-game: mostly new states
+    assert agent.check_status() == 0
+    del agent, env
+    release_cached_device_memory()
 
 
 @pytest.mark.parametrize("B", [1, 63, 2047, 2048, 2049, 4097, 6144])

@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), f"{name} declared in include/q2048.h but not exported"
     assert set(pkg._native._SIGNATURES) == declared
     L = pkg._native.lib()
-    assert L.q2048_abi_version() == pkg._native.ABI_VERSION == 2
+    assert L.q2048_abi_version() == pkg._native.ABI_VERSION == 3
     assert L.q2048_sizeof_aux() == 16 and L.q2048_sizeof_slot() == 32
     assert L.q2048_strerror(-4).decode().startswith("unsupported")
     # host-side argument validation needs no device
@@ -37,6 +37,16 @@ def test_abi_exports_every_declared_symbol(pkg):
                                  None, None, None) == -1
     assert L.q2048_q_choose(16, 99, 16, 4, 4, 0.5, 0, 0, 0, 0, 16, 16, None) == -2  # bad cap_log2
     assert L.q2048_q_choose(16, 20, 16, 4, 4, 1.5, 0, 0, 0, 0, 16, 16, None) == -6  # eps range
+    # flag bits outside the ABI are refused by the shipped library (-7), taken by the measurement build
+    assert L.q2048_q_choose(16, 20, 16, 4, 4, 0.5, 0, 0, 0, 1 << 9, 16, 16, None) == -7
+    assert L.q2048_fused_rollout(16, 16, 16, 20, 4, 4, 1, 0.5, 0.1, 0.9, 0, 0, 0, 1 << 12, None, None, 16,
+                                 None) == -7
+    assert L.q2048_det_rollout(16, 16, 16, 20, 4, 4, 1, 0.5, 0.1, 0.9, 0, 0, 0, pkg._native.FLAG_NO_LEARN,
+                               None, None, 16, 256, 1 << 20, None) == -7
+    assert b"flag" in L.q2048_strerror(-7)
+    X = pkg._native.load(pkg._native.build_experiments())        # same ABI, same symbols
+    for name in sorted(declared):
+        assert hasattr(X, name)
     # the deterministic mode's workspace is host arithmetic: pairs twice over, slots, long-run list, counts
     small, big = L.q2048_det_workspace_bytes(1, 20), L.q2048_det_workspace_bytes(1 << 20, 32)
     assert 0 < small < 1 << 20 and small % 256 == 0

@@ -227,11 +227,12 @@ def test_td_kat_from_survey(O):
 
 
 # ---- G6 / G7: whole-loop transcripts ------------------------------------------------------------
-def _replay(O, tr, decay):
+def _replay(O, tr, decay, storage_f32=False):
     B, seed, id0 = int(tr["B"]), int(tr["seed"]), int(tr["env_id0"])
     envs = O.envs_init(B, 4, seed, id0)
     agent = O.Agent(int(tr["E"]), 4, learning_rate=float(tr["lr"]),
-                    discount_factor=float(tr["gamma"]), exploration_rate=float(tr["eps0"]))
+                    discount_factor=float(tr["gamma"]), exploration_rate=float(tr["eps0"]),
+                    storage_f32=storage_f32)
     boards, acts, rews, dones, eps = [], [], [], [], []
     finished = 0
     for t in range(int(tr["steps"])):
@@ -266,6 +267,46 @@ def test_g6_transcripts(O, name):
     got = np.stack([agent.q(k) for k in tr["q_keys"]])
     assert np.array_equal(got, tr["q_vals"])             # float64 bit-exact Q-table
     assert dones.sum() == len(tr["ep_returns"])
+
+
+@pytest.mark.parametrize("name", ["g6_episodes_seed0", "g6_episodes_seed7", "g7_batched_b8"])
+def test_f32_storage_option(O, name):
+    """The oracle's float32-storage option (orc_agent_t.storage_f32: the device's table type, a
+    documented deviation from the reference's float64 dict) against the reference's own transcripts:
+    the same actions, boards and dones at every step, float32-rounded rewards, and a final dict
+    within the north star's 1e-5 of the reference's -- so it can stand in for the float64 agent where
+    argmax ties of a float32 table have to break as they do on the device."""
+    tr = load_npz(name + ".npz")
+    decay = bool(tr["decay"]) and int(tr["B"]) == 1
+    envs, agent, (boards, acts, rews, dones, eps) = _replay(O, tr, decay, storage_f32=True)
+    assert np.array_equal(boards, tr["boards"]) and np.array_equal(acts, tr["actions"])
+    assert np.array_equal(dones, tr["dones"])
+    assert np.array_equal(rews, tr["rewards"].astype(np.float32).astype(np.float64))
+    assert len(agent) == len(tr["q_keys"])
+    got = np.stack([agent.q(k) for k in tr["q_keys"]])
+    assert np.array_equal(got, got.astype(np.float32).astype(np.float64))      # rows hold float32 values
+    assert np.allclose(got, tr["q_vals"], rtol=1e-5, atol=1e-6)
+    assert not np.array_equal(got, tr["q_vals"])                               # and it is a different table
+    # the two-phase driver with B = 1 is the same loop: same table, float32 rounding once per step
+    if int(tr["B"]) == 1 and not decay:
+        envs2 = O.envs_init(1, 4, int(tr["seed"]), int(tr["env_id0"]))
+        a2 = O.Agent(int(tr["E"]), 4, learning_rate=float(tr["lr"]), discount_factor=float(tr["gamma"]),
+                     exploration_rate=float(tr["eps0"]), storage_f32=True)
+        O.rollout_sync(envs2, a2, int(tr["steps"]), int(tr["seed"]), int(tr["env_id0"]), 0)
+        assert np.array_equal(np.stack([a2.q(k) for k in tr["q_keys"]]), got)
+
+
+def test_random_play_rollout_without_agent(O):
+    """orc_rollout with neither agent nor actions = uniformly random play (the device's PLAY_ONLY
+    rollout at epsilon = 1): equal to an epsilon = 1 agent's trajectory, single- and multi-threaded."""
+    B, steps, seed, id0 = 300, 150, 11, 5
+    e1, e2, e3 = (O.envs_init(B, 4, seed, id0) for _ in range(3))
+    O.rollout(e1, O.Agent(10, 4, exploration_rate=1.0), steps, seed, id0, 0)
+    si, _ = O.rollout(e2, None, steps, seed, id0, 0)
+    si3, _ = O.rollout_mt(e3, None, steps, seed, id0, 0, threads=3)
+    for k in ("board", "score", "episode", "consecutive_count"):
+        assert np.array_equal(e1[k], e2[k]) and np.array_equal(e1[k], e3[k]), k
+    assert si[O.ST_STEPS] == si3[O.ST_STEPS] == B * steps and si[O.ST_EPISODES] == si3[O.ST_EPISODES] > 0
 
 
 # ---- G8: the DQN path's env profile (Game2048_nopenalty_env.py:106-138) -------------------------

@@ -4,6 +4,7 @@ import gc, importlib, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
+pkg._native.use_experiments_build()   # the measurement build: experiment bits 8..23 of `flags`
 MODES = {"store_plain": 0, "cas": 1, "store_sc1": 2, "add": 6, "none": 4}
 
 def run(name, bits, B=1 << 20, S=16, steps=128, warm=64, eps=0.95, cap_log2=32, warm_bits=None):

@@ -12,6 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
+pkg._native.use_experiments_build()   # the measurement build: experiment bits 8..23 of `flags`
 N = pkg._native
 dev = "cuda:0"
 for B, launches in ((1 << 20, 300), (8 << 20, 60)):

@@ -21,6 +21,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
+pkg._native.use_experiments_build()   # the measurement build: experiment bits 8..23 of `flags`
 
 p = argparse.ArgumentParser()
 p.add_argument("--num-envs", type=int, default=4096)
