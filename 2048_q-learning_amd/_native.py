@@ -101,6 +101,17 @@ _SIGNATURES = {
     "q2048_env_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                  C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "q2048_env_step_to": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                    C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "q2048_sizeof_rowcache": (C.c_size_t, [C.c_int]),
+    "q2048_q_choose_cached": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double,
+                                        C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "q2048_q_update_cached": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
+                                        C.c_double, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "q2048_env_step_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),

@@ -175,12 +175,16 @@ class BatchedQLearningAgent:
                     candidate allocations to probe.  `self.placement` is the report.
     strict_td       update Q[s][a] with a compare-and-swap loop (concurrent updates of one entry
                     serialise) instead of one store (last writer wins).  Same result whenever
-                    no two lanes share (s, a); several times slower when many lanes do."""
+                    no two lanes share (s, a); several times slower when many lanes do.
+    row_cache       `choose_action` / `update_q_value` hand the row an env read as next_state on to
+                    its next call through a device buffer of 32 B per env (q2048_*_cached: what the
+                    fused rollout carries in registers), so an update reads one scattered row instead
+                    of two.  Used only on a key match, so any calling pattern is correct."""
 
     def __init__(self, total_epochs, action_space=4, learning_rate=0.1, discount_factor=0.9,
                  exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 24,
                  device="cuda", seed: int = 0, env_id0: int = 0, independent: bool = False,
-                 strict_td: bool = False, board_size: int = 4, placement="auto"):
+                 strict_td: bool = False, board_size: int = 4, placement="auto", row_cache: bool = True):
         self.device = _require_gpu(device)
         if action_space != 4:
             raise ValueError("the 2048 action space has 4 actions")
@@ -204,6 +208,23 @@ class BatchedQLearningAgent:
         self.stats_f = torch.zeros(N.NSTAT_F, dtype=torch.float64, device=self.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.q_table = _QTableView(self)
+        self.row_cache_enabled = bool(row_cache)
+        self._row_cache = None
+
+    def _cache(self, B: int):
+        """The row cache for a batch of B envs (device pointer or None)."""
+        if not self.row_cache_enabled:
+            return None
+        c = self._row_cache
+        if c is None or c.shape[0] != B:
+            c = self._row_cache = torch.zeros((B, int(N.lib().q2048_sizeof_rowcache(self.board_size))),
+                                              dtype=torch.uint8, device=self.device)
+        return c
+
+    def invalidate_row_cache(self) -> None:
+        """After the table was changed by anything but choose_action / update_q_value."""
+        if self._row_cache is not None:
+            self._row_cache.zero_()
 
     # -- reference surface ---------------------------------------------------------------
     @property
@@ -226,9 +247,9 @@ class BatchedQLearningAgent:
         boards = self._boards(boards)
         B = boards.shape[0]
         actions = torch.empty(B, dtype=torch.uint8, device=self.device)
-        N.check(N.lib().q2048_q_choose(
+        N.check(N.lib().q2048_q_choose_cached(
             _ptr(self.table), self.capacity_log2, _ptr(boards), B, self.board_size, float(self.epsilon),
-            self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self.flags, _ptr(actions),
+            self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self.flags, _ptr(self._cache(B)), _ptr(actions),
             _ptr(self.status), _stream(self.device)), "q_choose")
         self.ctr += 1
         return actions
@@ -240,10 +261,11 @@ class BatchedQLearningAgent:
         actions = self._vec(actions, torch.uint8, B, "actions")
         reward = self._vec(reward, torch.float32, B, "reward")
         done = self._vec(done, torch.uint8, B, "done")
-        N.check(N.lib().q2048_q_update(
+        N.check(N.lib().q2048_q_update_cached(
             _ptr(self.table), self.capacity_log2, _ptr(boards), _ptr(actions), _ptr(reward),
             _ptr(next_boards), _ptr(done), B, self.board_size, float(self.lr), float(self.gamma), self.env_id0,
-            self.flags, _ptr(self.stats_i), _ptr(self.status), _stream(self.device)), "q_update")
+            self.flags, _ptr(self._cache(B)), _ptr(self.stats_i), _ptr(self.status), _stream(self.device)),
+            "q_update")
 
     def q_values(self, boards: torch.Tensor, env_id: int | None = None,
                  return_found: bool = False):
@@ -280,6 +302,7 @@ class BatchedQLearningAgent:
         if env.ctr != self.ctr:
             raise ValueError(f"env.ctr={env.ctr} and agent.ctr={self.ctr} are out of step")
         log = episode_log
+        self.invalidate_row_cache()
         N.check(N.lib().q2048_fused_rollout_log(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
             self.board_size, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
@@ -311,6 +334,7 @@ class BatchedQLearningAgent:
         if ws is None or ws.numel() < need + 256:
             ws = self._det_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = (ws.data_ptr() + 255) & ~255                       # the workspace is 256-byte aligned
+        self.invalidate_row_cache()
         N.check(L.q2048_det_rollout(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, B, self.board_size,
             int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed, self.env_id0,
@@ -399,6 +423,7 @@ class BatchedQLearningAgent:
         vars(self.schedule).update(sd["schedule"])
         self.stats_i.copy_(sd["stats_i"])
         self.stats_f.copy_(sd["stats_f"])
+        self.invalidate_row_cache()
         self.table.zero_()
         if "table" in sd:
             if sd["capacity_log2"] != self.capacity_log2:
@@ -413,6 +438,7 @@ class BatchedQLearningAgent:
         rows = len(q)
         if rows == 0:
             return
+        self.invalidate_row_cache()
         if rows * 2 > (1 << self.capacity_log2):
             raise ValueError("table too small for the checkpoint (load factor would exceed 0.5)")
         tk = torch.from_numpy(keys.view(np.int64)).to(self.device)
@@ -438,6 +464,8 @@ class BatchedQLearningAgent:
     def _vec(self, v, dtype, B, name) -> torch.Tensor:
         if not isinstance(v, torch.Tensor):
             v = torch.as_tensor(v)
+        if v.dtype == torch.bool and dtype == torch.uint8:
+            v = v.view(torch.uint8)                     # same bytes: no copy, no kernel
         v = v.to(device=self.device, dtype=dtype).contiguous()
         if v.shape != (B,):
             raise ValueError(f"{name} must have shape ({B},), got {tuple(v.shape)}")

@@ -138,6 +138,24 @@ __device__ __forceinline__ u64 key_hash(const Geo<5>::Key& k) {
 template <class Key>
 __device__ __forceinline__ u64 key_home(const Key& k, u64 mask) { return key_hash(k) & mask; }
 
+// Probe sequence of a key: BUCKETISED.  A miss moves the whole 128-byte line (4 slots) the probed
+// slot lies in, and what a lookup costs is the number of lines it touches, so a
+// collision is resolved inside the line already fetched: the sequence starts at the home slot
+// (hash & mask), visits the other three slots of that line cyclically -- L2 hits -- and only then
+// moves on to the next line, same order.  Plain linear probing left the line at the first collision
+// of every key whose home is a line's last slot.  (Slots are 32 B; with a 128-byte aligned table
+// a group of four is exactly one line.  Any 16-byte aligned table works.)
+struct Seq { u64 line0, lmask; uint32_t off; };
+__device__ __forceinline__ Seq seq_of(u64 hash, u64 mask) {
+  return Seq{(hash & mask) >> 2, mask >> 2, (uint32_t)hash & 3u};
+}
+__device__ __forceinline__ u64 seq_slot(const Seq& s, uint32_t p) {   // p-th slot of the sequence
+  return (((s.line0 + (u64)(p >> 2)) & s.lmask) << 2) | (u64)((s.off + p) & 3u);
+}
+__device__ __forceinline__ uint32_t seq_pos(const Seq& s, u64 slot) { // inverse, for a slot on the sequence
+  return ((uint32_t)(((slot >> 2) - s.line0) & s.lmask) << 2) | (((uint32_t)slot - s.off) & 3u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // hash table.  Readers use agent-scope relaxed loads (they bypass the per-CU L1, which other
 // CUs' atomics never refresh); rows are claimed with a device-scope compare-and-swap on the key
@@ -220,10 +238,11 @@ __device__ __forceinline__ u32x4 ld16_agent(const void* p) {  // waited for in p
 }
 __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
                                               const Geo<4>::Key& key, Row& row, bool& created) {
-  u64 i = key_home(key, mask);
+  const Seq sq = seq_of(key_hash(key), mask);
   created = false;
   row = Row{0.f, 0.f, 0.f, 0.f};
-  for (int p = 0; p < kMaxProbe; ++p) {
+  for (uint32_t p = 0; p < (uint32_t)kMaxProbe; ++p) {
+    const u64 i = seq_slot(sq, p);
     const u32x4 v = ld16_agent(&table[i]);
     const u64 k = (u64)v.x | ((u64)v.y << 32);
     if (k == key.k0) {
@@ -232,7 +251,6 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
       return (int64_t)i;
     }
     if (k == 0ull) return ~(int64_t)i;
-    i = (i + 1ull) & mask;
   }
   return kNoSlot;
 }
@@ -242,10 +260,11 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
 // is being created by its owner: wait for the word (`confirm`).
 __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
                                               const Geo<5>::Key& key, Row& row, bool& created) {
-  u64 i = key_home(key, mask);
+  const Seq sq = seq_of(key_hash(key), mask);
   created = false;
   row = Row{0.f, 0.f, 0.f, 0.f};
-  for (int p = 0; p < kMaxProbe; ++p) {
+  for (uint32_t p = 0; p < (uint32_t)kMaxProbe; ++p) {
+    const u64 i = seq_slot(sq, p);
     const u32x4 a = ld16_agent(&table[i]);
     const u64 k = (u64)a.x | ((u64)a.y << 32);
     if (k == 0ull) return ~(int64_t)i;
@@ -258,25 +277,23 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
         return (int64_t)i;
       }
     }
-    i = (i + 1ull) & mask;
   }
   return kNoSlot;
 }
 
-// Find-or-create starting at slot `start` (the hint of a failed probe_find, or the home slot).
-// The first access is the claiming compare-and-swap itself: the slot was empty a moment ago.
-// Returns the slot index or kNoSlot (probe limit: the caller drops the update).
+// Find-or-create starting at slot `start` of the key's sequence (the hint of a failed probe_find,
+// or the home slot).  The first access is the claiming compare-and-swap itself: the slot was empty
+// a moment ago.  Returns the slot index or kNoSlot (probe limit: the caller drops the update).
 template <class Key>
 __device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, const Key& key, u64 start,
                                                 bool& inserted) {
+  const Seq sq = seq_of(key_hash(key), mask);
   u64 i = start & mask;
   inserted = false;
-  u64 k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key.k0);
-  for (int p = 0; p < kMaxProbe; ++p) {
-    if ((k == 0ull || k == key.k0) && confirm(&table[i], key, k == 0ull, inserted)) return (int64_t)i;
-    i = (i + 1ull) & mask;
-    k = ld_u64(&table[i].key);
+  u64 k = 0ull;                                      // the hinted slot: straight to the compare-and-swap
+  for (uint32_t p = seq_pos(sq, i); p < (uint32_t)kMaxProbe; i = seq_slot(sq, ++p), k = ld_u64(&table[i].key)) {
     if (k == 0ull) k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key.k0);
+    if ((k == 0ull || k == key.k0) && confirm(&table[i], key, k == 0ull, inserted)) return (int64_t)i;
   }
   inserted = false;
   return kNoSlot;
@@ -311,7 +328,8 @@ __device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, co
   c.active = false;
   if (c.ret == 0ull) { inserted = true; return (int64_t)c.at; }
   if (c.ret == key.k0) return (int64_t)c.at;
-  return probe_insert(table, mask, key, c.at + 1ull, inserted);  // another key took the slot
+  const Seq sq = seq_of(key_hash(key), mask);                    // another key took the slot: go on
+  return probe_insert(table, mask, key, seq_slot(sq, seq_pos(sq, c.at) + 1u), inserted);
 }
 
 // update_q_value on one entry (Agent/main.py:43) against its CURRENT value.  `guess` is the
@@ -425,14 +443,20 @@ __global__ __launch_bounds__(kBlock) void k_env_init(uint8_t* boards, q2048_aux*
   if (i < B) st_aux(aux, i, a);
 }
 
+// Masked reset: a lane whose mask byte is 0 touches nothing (a 1 Mi-board call after a step resets
+// under 1 % of the lanes: the launch reads the mask and little else).  5x5 boards move through the
+// block's LDS image, so there the whole block leaves together when none of its lanes is masked.
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_env_reset(uint8_t* boards, q2048_aux* aux,
                                                       const uint8_t* mask, int64_t B, uint64_t seed,
                                                       uint64_t env_id0, uint32_t flags) {
   __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool mine = i < B && (mask == nullptr || mask[i] != 0);
+  if constexpr (N == 4) { if (!mine) return; }
+  else { if (__syncthreads_or(mine ? 1 : 0) == 0) return; }
   auto b = load_board(boards, i, B, st);
-  if (i < B && (mask == nullptr || mask[i] != 0)) {
+  if (mine) {
     Aux a = ld_aux(aux, i);
     begin_episode(b, a, seed, env_id0 + (uint64_t)i, (flags & Q2048_FLAG_RESET_SHAPING) != 0);
     st_aux(aux, i, a);
@@ -443,22 +467,27 @@ __global__ __launch_bounds__(kBlock) void k_env_reset(uint8_t* boards, q2048_aux
 // ENV: env profile bits (kEnvDqn: the DQN path's step).  draw_pos != nullptr: injected draws,
 // element i * draw_stride of draw_pos / draw_val (and, for kEnvDqn, draw_opos / draw_oval: the
 // spawn inside is_game_over's move).
+// boards_in / boards_out: the same buffer (in place) or two (the state before the step stays
+// intact for update_q_value: the batched loop needs no board copy).  max_tile (may be NULL): the
+// reference's `info`, the raw max tile (Game2048_env.py:100,129), next to its log2.
 template <int N, int ENV>
-__global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux* aux,
+__global__ __launch_bounds__(kBlock) void k_env_step(const uint8_t* boards_in, uint8_t* boards, q2048_aux* aux,
                                                      const uint8_t* actions, int64_t B, uint64_t seed,
                                                      uint64_t env_id0, uint32_t ctr, float* reward,
-                                                     uint8_t* done, uint8_t* max_l2, uint32_t* status,
+                                                     uint8_t* done, uint8_t* max_l2, int32_t* max_tile,
+                                                     uint32_t* status,
                                                      const uint32_t* draw_pos, const uint32_t* draw_val,
                                                      const uint32_t* draw_opos, const uint32_t* draw_oval,
                                                      int draw_stride) {
   __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  auto b = load_board(boards, i, B, st);
+  auto b = load_board(boards_in, i, B, st);
   if (i < B) {
     const int act = actions[i];
     if (act > 3) {  // rejected, never masked (Game2048_env.py:56-60 would mis-rotate)
       atomicOr(status, Q2048_STATUS_BAD_ACTION);
       reward[i] = 0.f; done[i] = 0; max_l2[i] = 0;
+      if (max_tile != nullptr) max_tile[i] = 0;
     } else {
       Aux a = ld_aux(aux, i);
       Draws x, y{0u, 0u, 0u, 0u};
@@ -472,6 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step(uint8_t* boards, q2048_aux*
       const StepOut o = env_step_profile<ENV>(b, a, act, x.x2, x.x3, y.x0, y.x1);
       st_aux(aux, i, a);
       reward[i] = o.reward; done[i] = o.done; max_l2[i] = o.max_log2;
+      if (max_tile != nullptr) max_tile[i] = o.max_log2 ? (int32_t)(1u << o.max_log2) : 0;
     }
   }
   store_board(boards, i, B, b, st);
@@ -529,11 +559,12 @@ __global__ __launch_bounds__(kBlock) void k_env_step4_pipelined(
 // takes 12.07 / 103.5 us (tools/exp_stream_floor.hip).
 template <int ENV>
 __global__ __launch_bounds__(kBlock) void k_env_step4(
-    uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, uint64_t seed,
-    uint64_t env_id0, uint32_t ctr, float* reward, uint8_t* done, uint8_t* max_l2, uint32_t* status) {
+    const uint8_t* boards_in, uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B,
+    uint64_t seed, uint64_t env_id0, uint32_t ctr, float* reward, uint8_t* done, uint8_t* max_l2,
+    int32_t* max_tile, uint32_t* status) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= B) return;
-  const uint4 bv = reinterpret_cast<const uint4*>(boards)[i];
+  const uint4 bv = reinterpret_cast<const uint4*>(boards_in)[i];
   const uint4 av = reinterpret_cast<const uint4*>(aux)[i];
   const uint32_t act = actions[i];
   // The three loads go out together: testing the action first would put its round trip in front
@@ -553,11 +584,14 @@ __global__ __launch_bounds__(kBlock) void k_env_step4(
   if (act > 3u) {  // rejected, never masked (Game2048_env.py:56-60 would mis-rotate); board and aux stay
     atomicOr(status, Q2048_STATUS_BAD_ACTION);
     reward[i] = 0.f; done[i] = 0; max_l2[i] = 0;
+    if (max_tile != nullptr) max_tile[i] = 0;
+    if (boards != boards_in) reinterpret_cast<uint4*>(boards)[i] = bv;
     return;
   }
   reinterpret_cast<uint4*>(boards)[i] = make_uint4(b.r0, b.r1, b.r2, b.r3);
   st_aux(aux, i, a);
   reward[i] = o.reward; done[i] = o.done; max_l2[i] = o.max_log2;
+  if (max_tile != nullptr) max_tile[i] = o.max_log2 ? (int32_t)(1u << o.max_log2) : 0;
 }
 
 // legal-move mask (mainDQL_CNN_step2.py:168-174): four trial moves per lane, nothing stored back
@@ -600,11 +634,59 @@ __global__ __launch_bounds__(kBlock) void k_encode_onehot(const uint8_t* boards,
 // ---------------------------------------------------------------------------------------------
 // agent kernels
 // ---------------------------------------------------------------------------------------------
+// Row cache of the 4-call API (optional, caller-owned, one record per env): what the fused rollout
+// carries in registers from one step to the next -- the row this env read as s' in its last
+// update, with its slot -- handed from one q_update call to the next q_choose / q_update through
+// HBM as a coalesced stream.  s of step t + 1 is s' of step t unless an episode began, so the
+// update then needs ONE scattered row read (s') instead of two, and a greedy choose none.  A
+// record is used only when its key equals the key of the board actually passed in (0 = empty), so
+// any calling pattern is correct; like the register-carried row it does not see what OTHER envs
+// wrote to that row since.
+template <int N> struct RowCache;
+template <> struct RowCache<4> { u64 key; float q[4]; u64 slot; };                      // 32 B
+template <> struct RowCache<5> { u64 key; float q[4]; u64 key_hi; u64 slot; u64 pad; }; // 48 B
+static_assert(sizeof(RowCache<4>) == 32 && sizeof(RowCache<5>) == 48, "ABI layout");
+
+__device__ __forceinline__ bool cache_get(const RowCache<4>* c, int64_t i, const Geo<4>::Key& key, Row& r,
+                                          int64_t& slot) {
+  const uint4* p = reinterpret_cast<const uint4*>(c + i);
+  const uint4 a = p[0], b = p[1];
+  if (((u64)a.x | ((u64)a.y << 32)) != key.k0) return false;
+  r = Row{bits_f32(a.z), bits_f32(a.w), bits_f32(b.x), bits_f32(b.y)};
+  slot = (int64_t)((u64)b.z | ((u64)b.w << 32));
+  return true;
+}
+__device__ __forceinline__ bool cache_get(const RowCache<5>* c, int64_t i, const Geo<5>::Key& key, Row& r,
+                                          int64_t& slot) {
+  const uint4* p = reinterpret_cast<const uint4*>(c + i);
+  const uint4 a = p[0], b = p[1], d = p[2];
+  if (((u64)a.x | ((u64)a.y << 32)) != key.k0 || ((u64)b.z | ((u64)b.w << 32)) != key.k1) return false;
+  r = Row{bits_f32(a.z), bits_f32(a.w), bits_f32(b.x), bits_f32(b.y)};
+  slot = (int64_t)((u64)d.x | ((u64)d.y << 32));
+  return true;
+}
+__device__ __forceinline__ void cache_put(RowCache<4>* c, int64_t i, const Geo<4>::Key& key, const Row& r,
+                                          int64_t slot) {
+  const u64 k = slot >= 0 ? key.k0 : 0ull;             // no row (table full): nothing to remember
+  uint4* p = reinterpret_cast<uint4*>(c + i);
+  p[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), f32_bits(r.q0), f32_bits(r.q1));
+  p[1] = make_uint4(f32_bits(r.q2), f32_bits(r.q3), (uint32_t)(u64)slot, (uint32_t)((u64)slot >> 32));
+}
+__device__ __forceinline__ void cache_put(RowCache<5>* c, int64_t i, const Geo<5>::Key& key, const Row& r,
+                                          int64_t slot) {
+  const u64 k = slot >= 0 ? key.k0 : 0ull;
+  uint4* p = reinterpret_cast<uint4*>(c + i);
+  p[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), f32_bits(r.q0), f32_bits(r.q1));
+  p[1] = make_uint4(f32_bits(r.q2), f32_bits(r.q3), (uint32_t)key.k1, (uint32_t)(key.k1 >> 32));
+  p[2] = make_uint4((uint32_t)(u64)slot, (uint32_t)((u64)slot >> 32), 0u, 0u);
+}
+
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_q_choose(const q2048_slot* table, u64 mask,
                                                      const uint8_t* boards, int64_t B, double eps,
                                                      uint64_t seed, uint64_t env_id0, uint32_t ctr,
-                                                     uint32_t flags, uint8_t* actions, uint32_t* status,
+                                                     uint32_t flags, const RowCache<N>* cache,
+                                                     uint8_t* actions, uint32_t* status,
                                                      const uint32_t* draw_eps, const uint32_t* draw_act) {
   __shared__ Stage<N> st;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -621,7 +703,9 @@ __global__ __launch_bounds__(kBlock) void k_q_choose(const q2048_slot* table, u6
   } else {
     Row r;
     bool made;
-    probe_find(table, mask, state_key(b, salt, status), r, made);
+    int64_t slot;
+    const auto key = state_key(b, salt, status);
+    if (cache == nullptr || !cache_get(cache, i, key, r, slot)) probe_find(table, mask, key, r, made);
     act = argmax4(r.q0, r.q1, r.q2, r.q3);
   }
   actions[i] = (uint8_t)act;
@@ -650,7 +734,8 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
                                                      const uint8_t* actions, const float* reward,
                                                      const uint8_t* s2, const uint8_t* done, int64_t B,
                                                      double lr, double gamma, uint64_t env_id0,
-                                                     uint32_t flags, int64_t* stats_i, uint32_t* status) {
+                                                     uint32_t flags, RowCache<N>* cache, int64_t* stats_i,
+                                                     uint32_t* status) {
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
   stats_clear(bs);
@@ -667,22 +752,32 @@ __global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask
       const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(env_id0 + (uint64_t)i) : 0ull;
       const auto key_s = state_key(b_s, salt, status);
       const auto key_n = state_key(b_n, salt, status);
-      // q_table[next_state] (Agent/main.py:41): the defaultdict creates the row, so do we
-      Row rn;
-      const int64_t slot_n = probe_find(table, mask, key_n, rn, ins_n);
-      if (slot_n < 0 && slot_n != kNoSlot) probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
-      const float max_next = max4(rn.q0, rn.q1, rn.q2, rn.q3);
-      // q_table[state][action] (:43)
+      const bool same = key_eq(key_n, key_s);
+      // q_table[state] (Agent/main.py:43): the row this env carried over from its last update, or a
+      // probe; the defaultdict creates the row when absent, so do we
       Row rs;
-      int64_t slot = probe_find(table, mask, key_s, rs, ins_s);
-      if (slot < 0 && slot != kNoSlot) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
+      int64_t slot = kNoSlot;
+      if (cache == nullptr || !cache_get(cache, i, key_s, rs, slot)) {
+        slot = probe_find(table, mask, key_s, rs, ins_s);
+        if (slot < 0 && slot != kNoSlot) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
+      }
+      // q_table[next_state] (:41), created when absent as well; an invalid move stays on the row of s
+      Row rn = rs;
+      int64_t slot_n = slot;
+      if (!same) {
+        slot_n = probe_find(table, mask, key_n, rn, ins_n);
+        if (slot_n < 0 && slot_n != kNoSlot) slot_n = probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
+      }
+      const float max_next = max4(rn.q0, rn.q1, rn.q2, rn.q3);
       if (slot >= 0) {
-        td_update(&table[slot], act, row_get(rs, act), reward[i], max_next, done[i] != 0, lr, gamma,
-                  tdc, td_mode_of(flags));
+        const float nq = td_update(&table[slot], act, row_get(rs, act), reward[i], max_next, done[i] != 0,
+                                   lr, gamma, tdc, td_mode_of(flags));
+        if (same) row_set(rn, act, nq);                  // the row it stays on just changed (:100)
       } else {
         dropped = true;
         atomicOr(status, Q2048_STATUS_TABLE_FULL);
       }
+      if (cache != nullptr) cache_put(cache, i, key_n, rn, slot_n);
     }
     const uint32_t n_ins = wave_count(ins_n) + wave_count(ins_s), n_drop = wave_count(dropped);
     if (tdc.retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)tdc.retries);
@@ -1624,22 +1719,27 @@ int q2048_env_reset(uint8_t* boards, q2048_aux* aux, const uint8_t* mask, int64_
   return q2048_env_reset_ex(boards, aux, mask, B, n, seed, env_id0, 0u, stream);
 }
 
-static int env_step_impl(uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, int n,
-                         uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, float* reward,
-                         uint8_t* done, uint8_t* max_log2, uint32_t* status,
-                         const uint32_t* draw_pos, const uint32_t* draw_val,
+static int env_step_impl(const uint8_t* boards_in, uint8_t* boards, q2048_aux* aux, const uint8_t* actions,
+                         int64_t B, int n, uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags,
+                         float* reward, uint8_t* done, uint8_t* max_log2, int32_t* max_tile,
+                         uint32_t* status, const uint32_t* draw_pos, const uint32_t* draw_val,
                          const uint32_t* draw_opos, const uint32_t* draw_oval, int draw_stride,
                          void* stream) {
   if (int e = check_batch(B, n)) return e;
   if (int e = check_flags(flags)) return e;
-  if (!boards || !aux || !actions || !reward || !done || !max_log2 || !status) return Q2048_ERR_NULL;
-  if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
+  if (!boards_in || !boards || !aux || !actions || !reward || !done || !max_log2 || !status) return Q2048_ERR_NULL;
+  if (!aligned16(boards_in) || !aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
+  if (boards_in != boards) {       // two buffers must not overlap (lanes of one block read and write at different times)
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(boards_in), a1 = reinterpret_cast<uintptr_t>(boards);
+    const uintptr_t len = (uintptr_t)B * (uintptr_t)(n * n);
+    if (a0 < a1 + len && a1 < a0 + len) return Q2048_ERR_ALIGN;
+  }
   if (B == 0) return Q2048_OK;
   if (n == 4 && draw_pos == nullptr) {
     unsigned blocks = grid_for(B);
-#ifdef Q2048_EXPERIMENTS   // bits 8..11: boards per thread (k_env_step4_pipelined)
+#ifdef Q2048_EXPERIMENTS   // bits 8..11: boards per thread (k_env_step4_pipelined, in place only)
     const int64_t per_thread = ((flags >> 8) & 15u) ? (int64_t)((flags >> 8) & 15u) : 1;
-    if (per_thread > 1) {
+    if (per_thread > 1 && boards_in == boards && max_tile == nullptr) {
       blocks = (unsigned)((B + kBlock * per_thread - 1) / (kBlock * per_thread));
       if (flags & Q2048_FLAG_ENV_DQN)
         hipLaunchKernelGGL(k_env_step4_pipelined<kEnvDqn>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
@@ -1651,24 +1751,24 @@ static int env_step_impl(uint8_t* boards, q2048_aux* aux, const uint8_t* actions
     }
 #endif
     if (flags & Q2048_FLAG_ENV_DQN)
-      hipLaunchKernelGGL(k_env_step4<kEnvDqn>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
-                         boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status);
+      hipLaunchKernelGGL(k_env_step4<kEnvDqn>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, boards_in,
+                         boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, max_tile, status);
     else
-      hipLaunchKernelGGL(k_env_step4<0>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
-                         boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, status);
+      hipLaunchKernelGGL(k_env_step4<0>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, boards_in,
+                         boards, aux, actions, B, seed, env_id0, ctr, reward, done, max_log2, max_tile, status);
     return launch_status();
   }
-  Q2048_LAUNCH_ENV(k_env_step, flags & Q2048_FLAG_ENV_DQN, n, B, stream, boards, aux, actions, B, seed,
-                   env_id0, ctr, reward, done, max_log2, status, draw_pos, draw_val, draw_opos,
-                   draw_oval, draw_stride);
+  Q2048_LAUNCH_ENV(k_env_step, flags & Q2048_FLAG_ENV_DQN, n, B, stream, boards_in, boards, aux, actions, B,
+                   seed, env_id0, ctr, reward, done, max_log2, max_tile, status, draw_pos, draw_val,
+                   draw_opos, draw_oval, draw_stride);
   return launch_status();
 }
 
 int q2048_env_step(uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, int n,
                    uint64_t seed, uint64_t env_id0, uint32_t ctr, float* reward, uint8_t* done,
                    uint8_t* max_log2, uint32_t* status, void* stream) {
-  return env_step_impl(boards, aux, actions, B, n, seed, env_id0, ctr, 0u, reward, done, max_log2,
-                       status, nullptr, nullptr, nullptr, nullptr, 1, stream);
+  return env_step_impl(boards, boards, aux, actions, B, n, seed, env_id0, ctr, 0u, reward, done, max_log2,
+                       nullptr, status, nullptr, nullptr, nullptr, nullptr, 1, stream);
 }
 
 int q2048_env_step_ex(uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B, int n,
@@ -1676,10 +1776,18 @@ int q2048_env_step_ex(uint8_t* boards, q2048_aux* aux, const uint8_t* actions, i
                       const uint32_t* draws4, float* reward, uint8_t* done, uint8_t* max_log2,
                       uint32_t* status, void* stream) {
   if (draws4 == nullptr)
-    return env_step_impl(boards, aux, actions, B, n, seed, env_id0, ctr, flags, reward, done, max_log2,
-                         status, nullptr, nullptr, nullptr, nullptr, 1, stream);
-  return env_step_impl(boards, aux, actions, B, n, 0, 0, 0, flags, reward, done, max_log2, status,
+    return env_step_impl(boards, boards, aux, actions, B, n, seed, env_id0, ctr, flags, reward, done, max_log2,
+                         nullptr, status, nullptr, nullptr, nullptr, nullptr, 1, stream);
+  return env_step_impl(boards, boards, aux, actions, B, n, 0, 0, 0, flags, reward, done, max_log2, nullptr, status,
                        draws4, draws4 + 1, draws4 + 2, draws4 + 3, 4, stream);
+}
+
+int q2048_env_step_to(const uint8_t* boards_in, uint8_t* boards_out, q2048_aux* aux, const uint8_t* actions,
+                      int64_t B, int n, uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags,
+                      float* reward, uint8_t* done, uint8_t* max_log2, int32_t* max_tile, uint32_t* status,
+                      void* stream) {
+  return env_step_impl(boards_in, boards_out, aux, actions, B, n, seed, env_id0, ctr, flags, reward, done,
+                       max_log2, max_tile, status, nullptr, nullptr, nullptr, nullptr, 1, stream);
 }
 
 int q2048_env_step_draws(uint8_t* boards, q2048_aux* aux, const uint8_t* actions,
@@ -1687,30 +1795,44 @@ int q2048_env_step_draws(uint8_t* boards, q2048_aux* aux, const uint8_t* actions
                          float* reward, uint8_t* done, uint8_t* max_log2, uint32_t* status,
                          void* stream) {
   if (!draw_pos || !draw_val) return Q2048_ERR_NULL;
-  return env_step_impl(boards, aux, actions, B, n, 0, 0, 0, 0u, reward, done, max_log2, status,
+  return env_step_impl(boards, boards, aux, actions, B, n, 0, 0, 0, 0u, reward, done, max_log2, nullptr, status,
                        draw_pos, draw_val, nullptr, nullptr, 1, stream);
 }
 
 static int q_choose_impl(const q2048_slot* table, int cap_log2, const uint8_t* boards, int64_t B,
                          int n, double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr,
-                         uint32_t flags, uint8_t* actions, uint32_t* status,
+                         uint32_t flags, const void* row_cache, uint8_t* actions, uint32_t* status,
                          const uint32_t* draw_eps, const uint32_t* draw_act, void* stream) {
   if (int e = check_batch(B, n)) return e;
   if (int e = check_flags(flags)) return e;
   if (int e = check_table(table, cap_log2)) return e;
   if (!boards || !actions || !status) return Q2048_ERR_NULL;
-  if (!aligned16(boards)) return Q2048_ERR_ALIGN;
+  if (!aligned16(boards) || !aligned16(row_cache)) return Q2048_ERR_ALIGN;
   if (!(eps >= 0.0 && eps <= 1.0)) return Q2048_ERR_RANGE;
   if (B == 0) return Q2048_OK;
-  Q2048_LAUNCH(k_q_choose, n, B, stream, table, (u64)((1ull << cap_log2) - 1ull), boards, B, eps,
-               seed, env_id0, ctr, flags, actions, status, draw_eps, draw_act);
+  const u64 mask = (1ull << cap_log2) - 1ull;
+  if (n == 4)
+    hipLaunchKernelGGL(k_q_choose<4>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table, mask,
+                       boards, B, eps, seed, env_id0, ctr, flags, static_cast<const RowCache<4>*>(row_cache),
+                       actions, status, draw_eps, draw_act);
+  else
+    hipLaunchKernelGGL(k_q_choose<5>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table, mask,
+                       boards, B, eps, seed, env_id0, ctr, flags, static_cast<const RowCache<5>*>(row_cache),
+                       actions, status, draw_eps, draw_act);
   return launch_status();
 }
 
 int q2048_q_choose(const q2048_slot* table, int cap_log2, const uint8_t* boards, int64_t B, int n,
                    double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags,
                    uint8_t* actions, uint32_t* status, void* stream) {
-  return q_choose_impl(table, cap_log2, boards, B, n, eps, seed, env_id0, ctr, flags, actions,
+  return q_choose_impl(table, cap_log2, boards, B, n, eps, seed, env_id0, ctr, flags, nullptr, actions,
+                       status, nullptr, nullptr, stream);
+}
+
+int q2048_q_choose_cached(const q2048_slot* table, int cap_log2, const uint8_t* boards, int64_t B, int n,
+                          double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags,
+                          const void* row_cache, uint8_t* actions, uint32_t* status, void* stream) {
+  return q_choose_impl(table, cap_log2, boards, B, n, eps, seed, env_id0, ctr, flags, row_cache, actions,
                        status, nullptr, nullptr, stream);
 }
 
@@ -1719,24 +1841,41 @@ int q2048_q_choose_draws(const q2048_slot* table, int cap_log2, const uint8_t* b
                          double eps, uint64_t env_id0, uint32_t flags, uint8_t* actions,
                          uint32_t* status, void* stream) {
   if (!draw_eps || !draw_act) return Q2048_ERR_NULL;
-  return q_choose_impl(table, cap_log2, boards, B, n, eps, 0, env_id0, 0, flags, actions, status,
+  return q_choose_impl(table, cap_log2, boards, B, n, eps, 0, env_id0, 0, flags, nullptr, actions, status,
                        draw_eps, draw_act, stream);
+}
+
+size_t q2048_sizeof_rowcache(int n) { return n == 4 ? sizeof(RowCache<4>) : n == 5 ? sizeof(RowCache<5>) : 0; }
+
+int q2048_q_update_cached(q2048_slot* table, int cap_log2, const uint8_t* boards_s, const uint8_t* actions,
+                          const float* reward, const uint8_t* boards_s2, const uint8_t* done, int64_t B,
+                          int n, double lr, double gamma, uint64_t env_id0, uint32_t flags,
+                          void* row_cache, int64_t* stats_i, uint32_t* status, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (int e = check_flags(flags)) return e;
+  if (int e = check_table(table, cap_log2)) return e;
+  if (!boards_s || !actions || !reward || !boards_s2 || !done || !status) return Q2048_ERR_NULL;
+  if (!aligned16(boards_s) || !aligned16(boards_s2) || !aligned16(row_cache)) return Q2048_ERR_ALIGN;
+  if (!(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
+  if (B == 0) return Q2048_OK;
+  const u64 mask = (1ull << cap_log2) - 1ull;
+  if (n == 4)
+    hipLaunchKernelGGL(k_q_update<4>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table, mask,
+                       boards_s, actions, reward, boards_s2, done, B, lr, gamma, env_id0, flags,
+                       static_cast<RowCache<4>*>(row_cache), stats_i, status);
+  else
+    hipLaunchKernelGGL(k_q_update<5>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table, mask,
+                       boards_s, actions, reward, boards_s2, done, B, lr, gamma, env_id0, flags,
+                       static_cast<RowCache<5>*>(row_cache), stats_i, status);
+  return launch_status();
 }
 
 int q2048_q_update(q2048_slot* table, int cap_log2, const uint8_t* boards_s, const uint8_t* actions,
                    const float* reward, const uint8_t* boards_s2, const uint8_t* done, int64_t B,
                    int n, double lr, double gamma, uint64_t env_id0, uint32_t flags,
                    int64_t* stats_i, uint32_t* status, void* stream) {
-  if (int e = check_batch(B, n)) return e;
-  if (int e = check_flags(flags)) return e;
-  if (int e = check_table(table, cap_log2)) return e;
-  if (!boards_s || !actions || !reward || !boards_s2 || !done || !status) return Q2048_ERR_NULL;
-  if (!aligned16(boards_s) || !aligned16(boards_s2)) return Q2048_ERR_ALIGN;
-  if (!(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
-  if (B == 0) return Q2048_OK;
-  Q2048_LAUNCH(k_q_update, n, B, stream, table, (u64)((1ull << cap_log2) - 1ull), boards_s, actions,
-               reward, boards_s2, done, B, lr, gamma, env_id0, flags, stats_i, status);
-  return launch_status();
+  return q2048_q_update_cached(table, cap_log2, boards_s, actions, reward, boards_s2, done, B, n, lr, gamma,
+                               env_id0, flags, nullptr, stats_i, status, stream);
 }
 
 int q2048_q_lookup(const q2048_slot* table, int cap_log2, const uint8_t* boards, int64_t B, int n,

@@ -48,7 +48,13 @@ class BatchedGame2048Env:
     aux     torch.uint8 [B, 16]  q2048_aux records (score, return, previous_max, streak, episode)
 
     Lane i is global env `env_id0 + i`; its random draws depend only on (seed, global id,
-    step counter), never on B or on how a batch is sharded over GPUs."""
+    step counter), never on B or on how a batch is sharded over GPUs.
+
+    `step` ping-pongs two board buffers: it reads the current one and writes the other, which
+    becomes `env.boards`.  The tensor that was `env.boards` before the call (what `reset()` or the
+    previous `step()` returned: the loop's `state`) therefore still holds the pre-step boards, intact
+    until the NEXT step -- `agent.update_q_value(state, a, r, next_state, done)` needs no
+    `state.clone()` (Agent/main.py:92-100 in batched form).  Rollout entry points work in place."""
 
     def __init__(self, num_envs: int, board_size: int = 4, device="cuda", seed: int = 0,
                  env_id0: int = 0, profile: str = "shaped", reset_shaping_state: bool = False,
@@ -88,16 +94,24 @@ class BatchedGame2048Env:
                 return torch.zeros(shape, dtype=dtype).pin_memory()
             return torch.zeros(shape, dtype=dtype, device=self.device)
 
-        self.boards = alloc((B, self.cells), torch.uint8)
+        # one buffer for the host-visible one-env adapter (its step is in place), two otherwise
+        self._bufs = [alloc((B, self.cells), torch.uint8) for _ in range(1 if self.host_visible else 2)]
+        self._cur = 0
         self.aux = alloc((B, 16), torch.uint8)
         self._reward = alloc(B, torch.float32)
         self._done = alloc(B, torch.uint8)
         self._max = alloc(B, torch.uint8)
+        self._max_tile = alloc(B, torch.int32)
         self.status = alloc(1, torch.int32)
         N.check(N.lib().q2048_env_init(_ptr(self.boards), _ptr(self.aux), B, self.board_size,
                                        self.seed, self.env_id0, _stream(self.device)), "env_init")
         if self.host_visible:
             torch.cuda.current_stream(self.device).synchronize()
+
+    @property
+    def boards(self) -> torch.Tensor:
+        """The current boards, uint8 [B, n*n] (the buffer the last step wrote)."""
+        return self._bufs[self._cur]
 
     # -- reference surface ---------------------------------------------------------------
     def reset(self, mask: torch.Tensor | None = None) -> torch.Tensor:
@@ -113,18 +127,21 @@ class BatchedGame2048Env:
 
     def step(self, actions: torch.Tensor):
         """Game2048_env.step (:97-129): returns (boards, reward[B] f32, done[B] bool,
-        max_tile[B] int32 raw tile value, the reference's `info`)."""
+        max_tile[B] int32 raw tile value, the reference's `info`).  The outputs are views of buffers
+        the next step overwrites; `boards` is the other board buffer (see the class docstring)."""
         actions = self._as_u8(actions, "actions")
-        N.check(N.lib().q2048_env_step_ex(
-            _ptr(self.boards), _ptr(self.aux), _ptr(actions), self.num_envs, self.board_size, self.seed,
-            self.env_id0, self.ctr & 0xFFFFFFFF, self.env_flags, None, _ptr(self._reward),
-            _ptr(self._done), _ptr(self._max), _ptr(self.status), _stream(self.device)), "env_step")
+        src = self._bufs[self._cur]
+        nxt = (self._cur + 1) % len(self._bufs)
+        N.check(N.lib().q2048_env_step_to(
+            _ptr(src), _ptr(self._bufs[nxt]), _ptr(self.aux), _ptr(actions), self.num_envs, self.board_size,
+            self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self.env_flags, _ptr(self._reward),
+            _ptr(self._done), _ptr(self._max), _ptr(self._max_tile), _ptr(self.status),
+            _stream(self.device)), "env_step")
+        self._cur = nxt
         self.ctr += 1
         if self.host_visible:                           # host tensors: the launch has to finish first
             torch.cuda.current_stream(self.device).synchronize()
-        max_tile = torch.bitwise_left_shift(torch.ones_like(self._max, dtype=torch.int32),
-                                            self._max.to(torch.int32))
-        return self.boards, self._reward, self._done.bool(), max_tile
+        return self.boards, self._reward, self._done.view(torch.bool), self._max_tile
 
     @property
     def score(self) -> torch.Tensor:
@@ -193,7 +210,7 @@ class BatchedGame2048Env:
         if not isinstance(t, torch.Tensor):
             t = torch.as_tensor(t)
         if t.dtype == torch.bool:
-            t = t.to(torch.uint8)
+            t = t.view(torch.uint8)                     # same bytes: no copy, no kernel
         if t.dtype != torch.uint8:
             if t.numel() and (int(t.min()) < 0 or int(t.max()) > 255):
                 raise ValueError(f"{name} out of range")

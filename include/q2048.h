@@ -20,6 +20,8 @@
  *              (Game2048_env.py:81-95).  16-byte aligned.
  *   - table    q2048_slot[1 << cap_log2]: open-addressed hash Q-table, the device form of
  *              `defaultdict(lambda: np.zeros(4))` (Agent/main.py:16).  Zero-filled = empty.
+ *              16-byte aligned; 128-byte alignment makes every group of four slots one memory
+ *              line, which is what the bucketised probe sequence is built for.
  *   - RNG      counter based: draws = Philox4x32-10(key = seed, counter = (global env id,
  *              step counter ctr, stream)); lane i has global env id env_id0 + i, so results do
  *              not depend on how a batch is sharded over GPUs.
@@ -199,6 +201,17 @@ int q2048_env_step_ex(uint8_t *boards, q2048_aux *aux, const uint8_t *actions, i
                       const uint32_t *draws4, float *reward, uint8_t *done, uint8_t *max_log2,
                       uint32_t *status, void *stream);
 
+/* q2048_env_step_ex (draws derived from (seed, id, ctr)) reading boards_in and writing boards_out:
+ * the same buffer (in place), or two buffers that do not overlap -- then the state before the step
+ * stays intact for update_q_value(state, ...) and the batched loop of Agent/main.py:92-100 needs no
+ * board copy (the host side ping-pongs two buffers).  A lane with a rejected action copies its
+ * board unchanged.  max_tile (may be NULL): int32[B], the reference's `info` -- the raw max tile
+ * (Game2048_env.py:100,129) -- written next to its log2. */
+int q2048_env_step_to(const uint8_t *boards_in, uint8_t *boards_out, q2048_aux *aux,
+                      const uint8_t *actions, int64_t B, int n, uint64_t seed, uint64_t env_id0,
+                      uint32_t ctr, uint32_t flags, float *reward, uint8_t *done, uint8_t *max_log2,
+                      int32_t *max_tile, uint32_t *status, void *stream);
+
 /* QLearningAgent.choose_action(state) (Agent/main.py:34-38) for B states: epsilon test and
  * random action from the step draws, else first-maximum argmax of the row (zeros if absent;
  * a lookup never inserts -- value-equivalent to the defaultdict). */
@@ -224,6 +237,28 @@ int q2048_q_update(q2048_slot *table, int cap_log2, const uint8_t *boards_s,
                    const uint8_t *done, int64_t B, int n, double lr, double gamma,
                    uint64_t env_id0, uint32_t flags, int64_t *stats_i, uint32_t *status,
                    void *stream);
+
+/* Row cache of the 4-call API: q2048_q_update / q2048_q_choose with a caller-owned device buffer of
+ * B records of q2048_sizeof_rowcache(n) bytes (32 for n = 4, 48 for n = 5; 16-byte aligned;
+ * zero-filled = empty; NULL = the plain entry points).  q_update leaves in record i the row env i
+ * read as next_state -- key, slot, the four values, with its own write folded in when the move was
+ * invalid -- and the next q_choose / q_update of the same env use it instead of probing when the
+ * board they are given has that key: in the loop of Agent/main.py:92-100 `state` IS the previous
+ * `next_state` unless an episode began, so an update costs one scattered row read instead of two
+ * and a greedy choose none.  This is what the fused rollout carries in registers, handed over
+ * through HBM as a stream; like it, a cached row does not see what OTHER envs wrote to it since.
+ * Any calling pattern is correct (a record is used only on a key match); the caller zero-fills the
+ * cache whenever the table is changed by other means (import, another rollout entry point). */
+size_t q2048_sizeof_rowcache(int n);
+int q2048_q_choose_cached(const q2048_slot *table, int cap_log2, const uint8_t *boards, int64_t B,
+                          int n, double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr,
+                          uint32_t flags, const void *row_cache, uint8_t *actions,
+                          uint32_t *status, void *stream);
+int q2048_q_update_cached(q2048_slot *table, int cap_log2, const uint8_t *boards_s,
+                          const uint8_t *actions, const float *reward, const uint8_t *boards_s2,
+                          const uint8_t *done, int64_t B, int n, double lr, double gamma,
+                          uint64_t env_id0, uint32_t flags, void *row_cache, int64_t *stats_i,
+                          uint32_t *status, void *stream);
 
 /* agent.q_table[state] (Agent/main.py:16,96) for B states: q_out[B][4] (zeros if absent),
  * found[B] (may be NULL). */

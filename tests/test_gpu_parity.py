@@ -593,6 +593,141 @@ def test_fused_equals_unfused_and_split_launches(pkg, O):
         assert s1[k] == s2[k], k
 
 
+@pytest.mark.parametrize("n", [4, 5])
+def test_four_call_loop_without_copies_and_row_cache(pkg, O, n):
+    """The batched loop of Agent/main.py:92-100 written WITHOUT a board copy (step ping-pongs two
+    buffers: the tensor that was env.boards stays the pre-step state) and with the row cache
+    (q2048_q_update_cached / q2048_q_choose_cached: s of step t + 1 is s' of step t) equals, bit for
+    bit, the same loop with clones and no cache, and the fused rollout; eps = 0.25 so that greedy
+    lanes read cached rows, 150 steps so that resets invalidate records.  Then the cache under
+    misuse: states passed in another order than the env's lanes -- a record is used only on a key
+    match, so the result is still the uncached one."""
+    B, steps, seed, id0, eps = 300, 150, 8, 999, 0.25
+
+    def mk(cache):
+        e = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+        a = pkg.BatchedQLearningAgent(100, exploration_rate=eps, discount_factor=0.95, capacity_log2=18,
+                                      seed=seed, env_id0=id0, device=DEV, independent=True, board_size=n,
+                                      row_cache=cache)
+        return e, a
+
+    e1, a1 = mk(False); _unfused_loop(pkg, e1, a1, steps)          # clones, no cache
+    e2, a2 = mk(True)
+    s = e2.reset()
+    for _ in range(steps):
+        a = a2.choose_action(s)
+        before = s.clone()
+        s2, r, d, info = e2.step(a)
+        assert s2.data_ptr() != s.data_ptr() and torch.equal(s, before)      # the state is intact
+        assert torch.equal(info, torch.where(e2.max_log2 > 0, 1 << e2.max_log2.int(), 0).int())
+        a2.update_q_value(s, a, r, s2, d)
+        s = e2.reset(d)
+    e3, a3 = mk(True); a3.fused_rollout(e3, steps)
+    assert torch.equal(e1.boards, e2.boards) and torch.equal(e1.aux, e2.aux) and torch.equal(e1.boards, e3.boards)
+    rows = [a.export_rows() for a in (a1, a2, a3)]
+    srt = [np.lexsort(k.reshape(len(q), -1).T[::-1]) for k, q in rows]
+    for (k, q), o in zip(rows[1:], srt[1:]):
+        assert np.array_equal(k[o], rows[0][0][srt[0]]) and np.array_equal(q[o], rows[0][1][srt[0]])
+    s1, s2_ = a1.stats(), a2.stats()
+    assert s1["inserts"] == s2_["inserts"] == a2.table_size() and a2.check_status() == 0
+    # misuse: every update is fed a random permutation of the lanes' transitions (private rows per
+    # lane POSITION, so the uncached result is well defined): records rarely match, and when they do
+    # they hold exactly that position's row
+    def shuffled(cache):
+        e = pkg.BatchedGame2048Env(B, board_size=n, seed=3, device=DEV)
+        a = pkg.BatchedQLearningAgent(100, exploration_rate=0.5, capacity_log2=18, seed=3, device=DEV,
+                                      board_size=n, row_cache=cache, independent=True)
+        g = torch.Generator(device="cpu"); g.manual_seed(5)
+        for t in range(60):
+            st = e.boards.clone()
+            act = a.choose_action(st)
+            nx, r, d, _ = e.step(act)
+            perm = (torch.randperm(B, generator=g) if t % 3 else torch.arange(B)).to(DEV)
+            a.update_q_value(st[perm], act[perm], r[perm], nx[perm], d[perm])
+            e.reset(d)
+        return e.boards.clone(), a.export_rows()
+    (b1, (k1, q1)), (b2, (k2, q2)) = shuffled(False), shuffled(True)
+    o1 = np.lexsort(k1.reshape(len(q1), -1).T[::-1]); o2 = np.lexsort(k2.reshape(len(q2), -1).T[::-1])
+    assert torch.equal(b1, b2) and np.array_equal(k1[o1], k2[o2]) and np.array_equal(q1[o1], q2[o2])
+
+
+def test_env_step_to_two_buffers(pkg):
+    """q2048_env_step_to: in place == two buffers; the input buffer is untouched; a rejected action
+    copies its board; overlapping buffers are refused; max_tile is the raw tile of max_log2."""
+    N, L = pkg._native, pkg._native.lib()
+    B, seed = 1000, 9
+    env = pkg.BatchedGame2048Env(B, seed=seed, device=DEV)
+    agent = pkg.BatchedQLearningAgent(10, exploration_rate=1.0, capacity_log2=4, seed=seed, device=DEV)
+    agent.fused_rollout(env, 60, play_only=True)
+    b0, aux0 = env.boards.clone(), env.aux.clone()
+    acts = torch.randint(0, 4, (B,), dtype=torch.uint8, device=DEV)
+    acts[7] = 9                                                     # rejected
+    outs = []
+    for two in (False, True):
+        bi, aux = b0.clone(), aux0.clone()
+        bo = torch.full_like(bi, 255) if two else bi
+        r = torch.zeros(B, device=DEV); d = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        m = torch.zeros(B, dtype=torch.uint8, device=DEV); mt = torch.zeros(B, dtype=torch.int32, device=DEV)
+        st = torch.zeros(1, dtype=torch.int32, device=DEV)
+        assert L.q2048_env_step_to(bi.data_ptr(), bo.data_ptr(), aux.data_ptr(), acts.data_ptr(), B, 4, seed, 0, 60,
+                                   0, r.data_ptr(), d.data_ptr(), m.data_ptr(), mt.data_ptr(), st.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        if two:
+            assert torch.equal(bi, b0)
+        assert int(st.item()) == N.STATUS_BAD_ACTION and torch.equal(bo[7], b0[7])
+        outs.append((bo.clone(), aux, r, d, m, mt))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    m, mt = outs[0][4], outs[0][5]
+    assert torch.equal(mt, torch.where(m > 0, 1 << m.int(), 0).int()) and int(mt.max()) >= 8
+    big = torch.zeros((B + 8, 16), dtype=torch.uint8, device=DEV)
+    assert L.q2048_env_step_to(big.data_ptr(), big.data_ptr() + 64, aux0.data_ptr(), acts.data_ptr(), B, 4, seed, 0,
+                               0, 0, outs[0][2].data_ptr(), outs[0][3].data_ptr(), m.data_ptr(), None,
+                               env.status.data_ptr(), None) == -3
+
+
+@pytest.mark.parametrize("n,load", [(4, 0.5), (4, 0.93), (5, 0.9)])
+def test_bucketised_probing_at_high_load(pkg, n, load):
+    """The probe sequence stays inside the 128-byte line of four slots before it moves to the next
+    line.  Random keys imported up to load 0.93 of a small table (chains many lines long), every one
+    found again with its own values, none twice, absent keys absent; then the same through racing
+    inserts of a rollout (key set == the set of states the envs visited, no duplicates)."""
+    N, L = pkg._native, pkg._native.lib()
+    cap_log2 = 14
+    rows = int(load * (1 << cap_log2))
+    rng = np.random.default_rng(7)
+    words = 1 if n == 4 else 2
+    keys = rng.integers(1, 1 << 62, size=(2 * rows, words), dtype=np.int64)
+    if words == 2:
+        keys |= np.int64(-(1 << 63))                      # 5x5 key words carry bit 63
+    keys = np.unique(keys, axis=0)[: rows + 500]
+    rng.shuffle(keys)
+    present, absent = keys[:rows], keys[rows:]
+    q = rng.standard_normal((rows, 4)).astype(np.float32)
+    agent = pkg.BatchedQLearningAgent(10, capacity_log2=cap_log2, device=DEV, board_size=n)
+    tk, tq = torch.from_numpy(present.copy()).to(DEV), torch.from_numpy(q).to(DEV)
+    st = torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert L.q2048_table_import(agent.table.data_ptr(), cap_log2, tk.data_ptr(), tq.data_ptr(), rows, words,
+                                st.data_ptr(), None) == 0
+    assert int(st.item()) == 0 and agent.table_size() == rows
+    k2, q2 = agent.export_rows()
+    k2 = k2.reshape(len(q2), -1).view(np.int64)
+    o1, o2 = np.lexsort(present.T[::-1]), np.lexsort(k2.T[::-1])
+    assert np.array_equal(present[o1], k2[o2]) and np.array_equal(q[o1], q2[o2])
+    # importing the same keys again overwrites in place: no second row for any key
+    assert L.q2048_table_import(agent.table.data_ptr(), cap_log2, tk.data_ptr(), tq.data_ptr(), rows, words,
+                                st.data_ptr(), None) == 0
+    assert agent.table_size() == rows
+    if n == 4:     # a 4x4 key is its board's 16 nibbles: look every key up through the board path
+        def boards_of(kk):
+            k = kk[:, 0].astype(np.uint64)
+            return np.stack([((k >> np.uint64(4 * c)) & np.uint64(15)).astype(np.uint8) for c in range(16)], axis=1)
+        got, found = agent.q_values(t8(boards_of(present)), return_found=True)
+        assert bool(found.all()) and np.array_equal(got.cpu().numpy(), q)
+        got, found = agent.q_values(t8(boards_of(absent)), return_found=True)
+        assert not bool(found.any()) and float(got.abs().max()) == 0.0
+
+
 def test_shared_table_pure_exploration_trajectories_exact(pkg, O):
     """eps = 1: actions come from the draws alone, so every board trajectory is independent of
     the (racy) shared table and must equal the oracle bit for bit at any batch size."""

@@ -18,13 +18,13 @@ for B in (1 << 20, 1 << 16):
                                       capacity_log2=32 if B == 1 << 20 else 28, seed=0, device=dev, placement="plain")
     agent.fused_rollout(env, 256, play_only=True)
 
-    def loop(steps):
+    def loop(steps):                      # Agent/main.py:92-100, :81 in batched form
+        s = env.boards
         for _ in range(steps):
-            s = env.boards.clone()
             a = agent.choose_action(s)
-            s2, r, d, _ = env.step(a)
+            s2, r, d, _ = env.step(a)     # writes the other board buffer: `s` stays intact, no copy
             agent.update_q_value(s, a, r, s2, d)
-            env.reset(d)
+            s = env.reset(d)
 
     loop(8)
     torch.cuda.synchronize()
@@ -32,7 +32,7 @@ for B in (1 << 20, 1 << 16):
     steps = 64
     e0.record(); loop(steps); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    print(json.dumps({"api": "4-call (choose, step, update, reset) + 1 board copy per step", "B": B, "steps": steps,
+    print(json.dumps({"api": "4-call (choose, step, update, reset)", "B": B, "steps": steps,
                       "us_per_step": round(ms * 1e3 / steps, 1), "env_steps_per_s": B * steps / ms * 1e3}), flush=True)
     agent.ctr = env.ctr
     e0.record(); agent.fused_rollout(env, steps); e1.record(); torch.cuda.synchronize()
