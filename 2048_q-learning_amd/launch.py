@@ -13,11 +13,14 @@ Two rules of the GPU pool shape it:
     not), and children are brand-new interpreters, never re-executions of the parent;
   * processes are stopped by their exact PID, never by pattern.
 
-This module imports nothing from the package (no torch, no ctypes): it is safe to import first.
+This module imports nothing from the package (no torch, nothing that touches HIP): it is safe to
+import first.
 """
 from __future__ import annotations
 
+import ctypes
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -45,8 +48,40 @@ def rank_env(rank: int, world_size: int, master_addr: str, master_port: int, bas
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world_size),
                 "LOCAL_WORLD_SIZE": str(world_size), "MASTER_ADDR": master_addr,
                 "MASTER_PORT": str(master_port)})
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+    # dmabuf IPC.  The GPU pool's operating notes: "the host driver only supports dmabuf IPC, and
+    # without it RCCL / CUDA-tensor sharing across processes fails with `hipIpcGetMemHandle: invalid
+    # argument`"; the pool exports the variable already, so this only matters when a caller hands in
+    # an environment built from scratch (`base`).  No N > 1 RCCL run of this repository exists yet
+    # (a lease has one GPU), so the setting is carried on the pool's word, not on a measurement.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return env
+
+
+def _die_with_parent():
+    """preexec_fn of the rank processes (Linux): SIGTERM when the launcher dies, however it dies --
+    a rank blocked in a collective would otherwise keep its GPU and its multi-GiB table until the
+    c10d timeout."""
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGTERM)      # PR_SET_PDEATHSIG
+    except Exception:                                                   # not Linux: nothing to set
+        pass
+
+
+def _stop(procs, grace_s: float = 5.0) -> None:
+    """Terminates exactly the PIDs in `procs` that still run: SIGTERM, SIGKILL after `grace_s`."""
+    for p in procs:
+        if p.poll() is None:
+            try:
+                p.terminate()
+            except OSError:
+                pass
+    t_end = time.monotonic() + grace_s
+    for p in procs:
+        try:
+            p.wait(max(0.0, t_end - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
 
 
 def launch_ranks(argv, nproc: int, master_addr: str = "127.0.0.1", master_port: int | None = None,
@@ -58,53 +93,67 @@ def launch_ranks(argv, nproc: int, master_addr: str = "127.0.0.1", master_port: 
     Rank 0's stdout is relayed line by line to `stdout` (default: this process's stdout) -- the
     one JSON line of bench.py; the other ranks' stdout goes to this process's stderr, as does
     every rank's stderr.  `line_filter(line) -> bool` selects which of rank 0's lines are relayed
-    (the rest go to stderr: gloo, for one, announces its connections on stdout).  When a rank exits non-zero, or `timeout` seconds pass, the remaining
-    ranks are terminated (SIGTERM to their PIDs, SIGKILL after 5 s) and the result is non-zero.
-    Returns 0 iff every rank exited 0."""
+    (the rest go to stderr: gloo, for one, announces its connections on stdout).  When a rank exits
+    non-zero, `timeout` seconds pass, or the launcher itself receives SIGTERM / SIGINT, the remaining
+    ranks are terminated (SIGTERM to their PIDs, SIGKILL after 5 s) and the result is non-zero; the
+    ranks also get SIGTERM from the kernel if the launcher dies without running its handlers
+    (PR_SET_PDEATHSIG).  Returns 0 iff every rank exited 0."""
     if nproc < 1:
         raise ValueError("nproc must be >= 1")
     out = sys.stdout if stdout is None else stdout
     port = free_port(master_addr) if master_port is None else int(master_port)
     procs = []
-    for r in range(nproc):
-        procs.append(subprocess.Popen(
-            list(argv), env=rank_env(r, nproc, master_addr, port, env),
-            stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-
-    def relay():
-        for line in procs[0].stdout:
-            dst = out if line_filter is None or line_filter(line) else sys.stderr
-            dst.write(line)
-            dst.flush()
-
-    pump = threading.Thread(target=relay, daemon=True)
-    pump.start()
-    deadline = None if timeout is None else time.monotonic() + timeout
     worst, failed = 0, False
-    while True:
-        codes = [p.poll() for p in procs]
-        if any(c not in (None, 0) for c in codes):
-            failed = True
-            worst = next(c for c in codes if c not in (None, 0))
-            break
-        if all(c == 0 for c in codes):
-            break
-        if deadline is not None and time.monotonic() > deadline:
-            failed, worst = True, 124
-            break
-        time.sleep(poll_s)
-    if failed:
-        for p in procs:                       # exactly the PIDs started above
-            if p.poll() is None:
-                p.terminate()
-        t_end = time.monotonic() + 5.0
-        for p in procs:
-            try:
-                p.wait(max(0.0, t_end - time.monotonic()))
-            except subprocess.TimeoutExpired:
-                p.kill()
-                p.wait()
-    pump.join(timeout=5.0)
+
+    class _Signalled(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Signalled(signum)
+
+    # SIGTERM / SIGINT to the launcher (a test's subprocess timeout, a scheduler, ^C) must not orphan
+    # the ranks: the handler unwinds into the finally below, which stops them
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            old_handlers[sig] = signal.signal(sig, on_signal)
+    pump = None
+    try:
+        for r in range(nproc):
+            procs.append(subprocess.Popen(
+                list(argv), env=rank_env(r, nproc, master_addr, port, env),
+                stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True,
+                preexec_fn=_die_with_parent))
+
+        def relay():
+            for line in procs[0].stdout:
+                dst = out if line_filter is None or line_filter(line) else sys.stderr
+                dst.write(line)
+                dst.flush()
+
+        pump = threading.Thread(target=relay, daemon=True)
+        pump.start()
+        deadline = None if timeout is None else time.monotonic() + timeout
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                failed = True
+                worst = next(c for c in codes if c not in (None, 0))
+                break
+            if all(c == 0 for c in codes):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                failed, worst = True, 124
+                break
+            time.sleep(poll_s)
+    except _Signalled as sig:
+        failed, worst = True, 128 + int(sig.args[0])
+    finally:
+        _stop(procs)                          # exactly the PIDs started above; a no-op when all have exited
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
+    if pump is not None:
+        pump.join(timeout=5.0)
     if failed:
         return worst if worst > 0 else 1      # a signal's negative code is still a failure
     return 0

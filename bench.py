@@ -29,13 +29,20 @@ Extra objects on the line:
                 with HIP events on the launching stream, against the 8 TB/s HBM3E peak; `traffic`
                 only when the committed PMC passes were taken with this run's configuration.
   cpu_baseline  the CPU oracle (a C port of the reference loop, oracle/) timed on this host's
-                cores on a bounded sample of the same workload (rank 0, N = 1 only): all cores
-                and one thread, with the CPU model.
-  companions    the same protocol at SURVEY 8(d)'s 2^28-slot table and at eps = 0.01 (N = 1 only).
+                cores on a bounded sample of the same workload (rank 0, after the GPU regions, at
+                every N): all cores and one thread, with the CPU model.
+  companions    the same protocol at SURVEY 8(d)'s 2^28-slot table, at eps = 0.01 and on 5x5 boards
+                (N = 1 only).
+
+`--check-shards` is a different job (no timing): every rank plays K steps of its shard at eps = 1
+and rank 0 prints 64-bit hashes of boards + aux per 4096 global env ids -- equal lists for N = 1
+and N = 2 over the same global ids prove, across processes, that a trajectory does not depend on
+how the batch is sharded (tests/test_gpu_parity.py::test_check_shards_across_processes).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib
 import importlib.util
 import json
@@ -56,7 +63,18 @@ ALGO_BYTES_FUSED_5X5 = 156
 ALGO_BYTES_ROW_TUPLE = 64 + 8 * 16 + 4 * 4 + 6
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
-PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r02_pmc_traffic.json", "r02_pmc_traffic_k20.json")]
+PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r03_pmc_traffic.json", "r03_pmc_traffic_k20.json")]
+CSRC = os.path.join(REPO, "2048_q-learning_amd", "csrc")
+KERNEL_SOURCES = ("q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc")
+
+
+def kernel_sources_sha16() -> str:
+    """Identifies the kernels a counter profile was taken on: SHA-256 over the HIP sources."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse_args(argv=None):
@@ -89,7 +107,12 @@ def parse_args(argv=None):
     p.add_argument("--experiment-bits", type=lambda v: int(v, 0), default=0,
                    help="unstable tuning bits OR-ed into the fused kernel's flags (ablations; not ABI)")
     p.add_argument("--no-companions", action="store_true",
-                   help="skip the 2^28-slot and eps = 0.01 companion runs (N = 1 only anyway)")
+                   help="skip the 2^28-slot, eps = 0.01 and 5x5 companion runs (N = 1 only anyway)")
+    p.add_argument("--check-shards", action="store_true",
+                   help="no timing: play --steps steps at eps = 1 and print per-chunk hashes of boards + aux "
+                        "(compare N = 1 with N = 2 over the same global env ids)")
+    p.add_argument("--launch-timeout", type=float, default=3000.0,
+                   help="self-launched ranks (--gpus N > 1 outside torchrun) are stopped after this many seconds")
     return p.parse_args(argv)
 
 
@@ -104,18 +127,20 @@ def load_launcher():
 
 def committed_pmc_traffic(cfg: dict):
     """(bytes per env-step, source, None) when one of the committed rocprofv3 PMC profiles
-    (profiles/r02_pmc_traffic*.json: the SURVEY protocol's 64-step launches, the driver's single
-    20-step launch) was taken with this run's configuration, else (None, None, the configurations
-    they were taken with)."""
+    (profiles/r03_pmc_traffic*.json: the SURVEY protocol's 64-step launches, the driver's single
+    20-step launch) was taken with this run's configuration AND on these kernel sources
+    (`kernel_sources_sha16`, written by tools/pmc_summary.py on the box that ran the passes), else
+    (None, None, what the committed passes were taken with)."""
     seen = []
+    sha = kernel_sources_sha16()
     for path in PMC_TRAFFIC_FILES:
         try:
             with open(path) as fh:
                 pmc = json.load(fh)
         except (OSError, ValueError):
             continue
-        have = pmc.get("config", {})
-        if all(have.get(k) == v for k, v in cfg.items()):
+        have = dict(pmc.get("config", {}), kernel_sources_sha16=pmc.get("kernel_sources_sha16"))
+        if all(have.get(k) == v for k, v in cfg.items()) and have["kernel_sources_sha16"] == sha:
             return pmc["bytes_per_env_step"], pmc["source"], None
         seen.append(have)
     return None, None, (seen[0] if len(seen) == 1 else seen) if seen else None
@@ -173,10 +198,11 @@ def cpu_baseline(args, seconds: float) -> dict:
 
 
 def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, steps, warmup, repeats,
-            S, reducer):
+            S, reducer, board_size=None):
     """The protocol of the module docstring for one configuration.  Returns a dict of raw
     measurements (region times are MAX over ranks)."""
-    env = pkg.BatchedGame2048Env(shard.num_envs, board_size=args.board_size, seed=args.seed,
+    board_size = args.board_size if board_size is None else board_size
+    env = pkg.BatchedGame2048Env(shard.num_envs, board_size=board_size, seed=args.seed,
                                  env_id0=shard.env_id0, device=dev)
     if args.agent == "row-tuple":
         agent = pkg.BatchedRowTupleAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
@@ -189,7 +215,7 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
         agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
                                           exploration_rate=eps, capacity_log2=cap_log2,
                                           seed=args.seed, env_id0=shard.env_id0, device=dev,
-                                          strict_td=args.strict_td, board_size=args.board_size,
+                                          strict_td=args.strict_td, board_size=board_size,
                                           placement=placement)
         synth = agent
         agent.experiment_bits = args.experiment_bits
@@ -377,39 +403,111 @@ def run_rank(args):
     }
 
     if world == 1 and args.agent == "hash" and not args.no_companions:
-        # the 2^28-slot table the survey specified and the exploit-heavy eps = 0.01
-        # run; each sized so that its table ends below load 0.5
+        # the 2^28-slot table the survey specified, the exploit-heavy eps = 0.01 run,
+        # and BASELINE configs[4] (5x5 boards, 156 algorithmic bytes per env-step); each sized so
+        # that its table ends below load 0.5
         comps = []
-        for name, c_eps, c_cap in (("capacity 2^28 (SURVEY 8(d))", args.eps, 28),
-                                   ("epsilon 0.01 (argmax path)", 0.01, cap_log2)):
+        for name, c_eps, c_cap, c_n in (("capacity 2^28 (SURVEY 8(d))", args.eps, 28, args.board_size),
+                                        ("epsilon 0.01 (argmax path)", 0.01, cap_log2, args.board_size),
+                                        ("5x5 boards (BASELINE configs[4])", args.eps, cap_log2, 5)):
+            if c_n == args.board_size and name.startswith("5x5"):
+                continue
             budget = int(0.5 * (1 << c_cap) / (0.75 * B))          # learning steps the table can take
             c_rep = 3
             c_steps = max(1, min(args.steps, budget // (c_rep + 1)))
             c_warm = max(1, min(args.warmup, budget - c_rep * c_steps))
             c_S = max(1, min(S, c_steps))
+            c_bytes = ALGO_BYTES_FUSED_4X4 if c_n == 4 else ALGO_BYTES_FUSED_5X5
             cm = measure(pkg, torch, args, dev, shard, world, eps=c_eps, cap_log2=c_cap,
-                         placement="plain" if c_cap < 31 else args.placement, steps=c_steps,
-                         warmup=c_warm, repeats=c_rep, S=c_S, reducer=reducer)
-            cs = summarise(cm, shard, c_steps, algo_bytes)
+                         placement=args.placement, steps=c_steps, warmup=c_warm, repeats=c_rep, S=c_S,
+                         reducer=reducer, board_size=c_n)
+            cs = summarise(cm, shard, c_steps, c_bytes)
             cst = cs["median_region"]["stats"]
-            comps.append({"name": name, "epsilon": c_eps, "table_capacity_log2": c_cap,
+            comps.append({"name": name, "epsilon": c_eps, "table_capacity_log2": c_cap, "board_size": c_n,
                           "steps": c_steps, "warmup": c_warm, "repeats": c_rep,
                           "steps_per_launch": c_S, "value": cs["value"],
                           "ms_per_step": cs["ms_per_step"], "region_ms": cs["region_ms"],
+                          "algorithmic_bytes_per_env_step": c_bytes,
                           "roofline_frac": cs["achieved_gbs"] / HBM_PEAK_GBS,
                           "inserts_per_step": cst["inserts"] / max(cst["steps"], 1),
-                          "episodes": cst["episodes"],
+                          "episodes": cst["episodes"], "table_placement": cm["placement"],
                           "table_load_factor": cm["table_rows"] / float(1 << c_cap)})
         out["companions"] = comps
 
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-    elif rank == 0:
-        out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # the GPU side is done: leave the process group before the host-only leg, so that no rank
+    # waits in a collective while rank 0 times the CPU
     if torch.distributed.is_initialized():
+        pkg.dist.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # the reference's CPU path next to the GPU number, on this node's cores, at every N
+        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds) if args.cpu_seconds > 0 else None
+        print(json.dumps(out), flush=True)
+
+
+SHARD_CHUNK = 4096
+
+
+def check_shards(args):
+    """`--check-shards`: every rank plays `--steps` steps of its contiguous shard of global env ids
+    at eps = 1 (actions are draws: trajectories do not depend on the table) and hashes boards + aux
+    per chunk of SHARD_CHUNK global ids; rank 0 prints all chunks in id order.  The same list for
+    any world size over the same ids = a trajectory does not depend on the sharding."""
+    import numpy as np
+    import torch
+
+    pkg = importlib.import_module("2048_q-learning_amd")
+    rank, local_rank, world = pkg.dist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    shard = pkg.weak_shard(args.boards_per_gpu, world, rank)
+    if shard.num_envs % SHARD_CHUNK:
+        raise SystemExit(f"--boards-per-gpu must be a multiple of {SHARD_CHUNK}")
+    env = pkg.BatchedGame2048Env(shard.num_envs, board_size=args.board_size, seed=args.seed,
+                                 env_id0=shard.env_id0, device=dev)
+    cap = args.cap_log2 or max(16, int(np.ceil(np.log2(2.0 * shard.num_envs * args.steps))))
+    agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
+                                      exploration_rate=1.0, capacity_log2=cap, seed=args.seed,
+                                      env_id0=shard.env_id0, device=dev, board_size=args.board_size,
+                                      placement="plain")
+    left = args.steps
+    while left > 0:
+        k = min(args.steps_per_launch, left)
+        agent.fused_rollout(env, k)
+        left -= k
+    cells = args.board_size ** 2
+    b = torch.zeros((shard.num_envs, 32), dtype=torch.uint8, device=dev)
+    b[:, :cells] = env.boards
+    words = torch.cat([b.view(torch.int64), env.aux.view(torch.int64)], dim=1)          # [B, 6]
+    consts = (0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, 0x27D4EB2F165667C5,
+              0x85EBCA77C2B2AE63, 0xFF51AFD7ED558CCD)
+    mult = torch.tensor([c - (1 << 64) if c >> 63 else c for c in consts], dtype=torch.int64, device=dev)
+    ids = torch.arange(shard.num_envs, dtype=torch.int64, device=dev) + shard.env_id0
+    h = (words * mult).sum(dim=1) ^ (ids * 0x2545F4914F6CDD1D)                            # wraps mod 2^64
+    h = (h ^ (h >> 29)) * -0x61C8864680B583EB
+    chunks = h.view(-1, SHARD_CHUNK).sum(dim=1).cpu().numpy().view(np.uint64)
+    st = agent.stats()
+    mine = {"rank": rank, "env_id0": shard.env_id0, "hashes": [f"{int(x):016x}" for x in chunks],
+            "episodes": st["episodes"], "steps": st["steps"], "status": agent.check_status()}
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, mine)
+        pkg.dist.barrier()
+        torch.distributed.destroy_process_group()
+    else:
+        gathered = [mine]
+    if rank == 0:
+        gathered.sort(key=lambda g: g["env_id0"])
+        print(json.dumps({"check_shards": True, "n_gpus": world, "total_envs": shard.total_envs,
+                          "steps": args.steps, "chunk": SHARD_CHUNK, "board_size": args.board_size,
+                          "seed": args.seed, "hashes": sum((g["hashes"] for g in gathered), []),
+                          "episodes": sum(g["episodes"] for g in gathered),
+                          "env_steps": sum(g["steps"] for g in gathered),
+                          "status": max(g["status"] for g in gathered)}), flush=True)
 
 
 def main(argv=None):
@@ -422,9 +520,12 @@ def main(argv=None):
         # the parent of the job: it has made no GPU call, starts one fresh process per rank,
         # relays rank 0's JSON line and exits with the ranks' worst code
         cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
-        raise SystemExit(launcher.launch_ranks(cmd, args.gpus,
+        raise SystemExit(launcher.launch_ranks(cmd, args.gpus, timeout=args.launch_timeout,
                                                line_filter=lambda ln: ln.lstrip().startswith("{")))
-    run_rank(args)
+    if args.check_shards:
+        check_shards(args)
+    else:
+        run_rank(args)
 
 
 if __name__ == "__main__":

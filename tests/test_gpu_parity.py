@@ -1735,9 +1735,50 @@ def test_bench_self_launched_two_ranks_share_one_gpu():
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == K and rec["warmup"] == 8
     assert rec["config"]["total_boards"] == 2 * B and rec["config"]["boards_per_gpu"] == B
     assert rec["stats"]["episodes"] > 0 and rec["stats"]["drops"] == 0 and rec["stats"]["status"] == 0
-    assert rec["cpu_baseline"] is None and "companions" not in rec
+    assert rec["cpu_baseline"] is None and "companions" not in rec          # --cpu-seconds 0
     assert len(rec["region_ms"]) == 3 and rec["value"] > 0
     assert abs(rec["value"] - 2 * B * K / (rec["ms_per_step"] * K / 1e3)) < 1e-6 * rec["value"]
+    # the CPU path is timed beside the GPU number at N > 1 too (rank 0, after the GPU regions)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "8",
+                        "--warmup", "4", "--boards-per-gpu", str(1 << 14), "--cap-log2", "22", "--prep-steps", "256",
+                        "--repeats", "2", "--cpu-seconds", "1.5"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert rec["n_gpus"] == 2 and rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["value"] > 1e5
+    assert rec["cpu_baseline"]["cores"] >= 1 and "single_thread" in rec["cpu_baseline"]
+
+
+def test_check_shards_across_processes():
+    """World-size invariance proved ACROSS PROCESSES: `bench.py --check-shards` with one rank on
+    32 768 boards and with two self-launched ranks (gloo; both on this box's one GPU) on 16 384 boards
+    each -- the same global env ids 0..32767 -- prints the same 64-bit hash of boards + aux for every
+    chunk of 4096 ids after 300 steps (episodes end and reset on the way); another seed does not."""
+    release_cached_device_memory()
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["Q2048_DIST_BACKEND"] = "gloo"
+
+    def run(gpus, per_gpu, seed=0, n=4):
+        p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--check-shards",
+                            "--steps", "300", "--boards-per-gpu", str(per_gpu), "--seed", str(seed),
+                            "--board-size", str(n)], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    one, two = run(1, 32768), run(2, 16384)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and one["total_envs"] == two["total_envs"] == 32768
+    assert len(one["hashes"]) == 8 and one["hashes"] == two["hashes"] and len(set(one["hashes"])) == 8
+    assert one["episodes"] == two["episodes"] > 1000 and one["env_steps"] == two["env_steps"] == 32768 * 300
+    assert one["status"] == two["status"] == 0
+    assert run(1, 32768, seed=1)["hashes"] != one["hashes"]
+    five1, five2 = run(1, 8192, n=5), run(2, 4096, n=5)
+    assert five1["hashes"] == five2["hashes"] and len(five1["hashes"]) == 2
 
 
 def test_bench_under_torchrun_one_rank_drives_rccl():
@@ -1828,6 +1869,49 @@ def test_train_save_then_evaluate_scripts(tmp_path):
     p = run(os.path.join(REPO, "train.py"), "--num-envs", "4096", "--episodes", "1", "--steps-per-launch", "32",
             "--report-every", "4", "--capacity-log2", "24", "--resume", model, "--log", str(tmp_path / "t2.csv"))
     assert p.returncode == 0, p.stderr[-2000:]
+
+
+def test_train_resume_continues_the_run(tmp_path):
+    """`train.py --stop-epoch k --save` then `--resume ... --episodes N` trains what one N-epoch run
+    trains (resume used to restart the epoch counter and replay the decay on an epsilon
+    that was already decayed).  Deterministic mode makes the runs reproducible, so the check is
+    exact: the resumed run's report rows (epoch, episodes, env-steps, epsilon, mean return, rows)
+    are the uninterrupted run's rows from the stop on, and the final tables are bit-identical.
+    A resume with a LONGER schedule than the saved run's keeps decaying instead of being pinned at
+    epsilon_min by the saved run's limits."""
+    release_cached_device_memory()
+    import csv
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    common = ["--num-envs", "512", "--steps-per-launch", "32", "--report-every", "1", "--capacity-log2", "22",
+              "--deterministic", "--epsilon", "0.9", "--seed", "3"]
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(REPO, "train.py"), *common, *a],  # noqa: E731
+                                    capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    rows = lambda f: [r[:8] for r in list(csv.reader(open(tmp_path / f)))[1:]]  # noqa: E731  (Drops, Steps/s left out)
+    p = run("--episodes", "10", "--save", "full.pt", "--log", "full.csv")
+    assert p.returncode == 0, p.stderr[-2000:]
+    p = run("--episodes", "10", "--stop-epoch", "4", "--save", "part.pt", "--log", "p1.csv")
+    assert p.returncode == 0, p.stderr[-2000:]
+    p = run("--episodes", "10", "--resume", "part.pt", "--save", "resumed.pt", "--log", "p2.csv")
+    assert p.returncode == 0, p.stderr[-2000:]
+    full, p1, p2 = rows("full.csv"), rows("p1.csv"), rows("p2.csv")
+    assert int(p1[-1][0]) >= 4 and int(p1[-1][0]) < 10 and len(p2) > 3
+    assert p1 + p2 == full                                       # same epochs, episodes, steps, epsilon trace, returns
+    assert int(full[-1][0]) == 10 and len({r[3] for r in full}) >= 8          # epsilon really moved
+    a, b = (torch.load(tmp_path / f, map_location="cpu", weights_only=False) for f in ("full.pt", "resumed.pt"))
+    oa, ob = np.argsort(a["keys"]), np.argsort(b["keys"])
+    assert np.array_equal(a["keys"][oa], b["keys"][ob]) and np.array_equal(a["q"][oa], b["q"][ob])
+    assert a["train"]["epoch"] == b["train"]["epoch"] == 10 and a["schedule"]["epsilon"] == b["schedule"]["epsilon"]
+    # a longer schedule on resume: limits come from the new --episodes
+    p = run("--episodes", "40", "--resume", "part.pt", "--stop-epoch", "8", "--log", "p3.csv")
+    assert p.returncode == 0, p.stderr[-2000:]
+    eps3 = [float(r[3]) for r in rows("p3.csv")]
+    # epochs 4..7 of a 40-epoch schedule are its first phase (floor 1.5 * epsilon_min = 0.015, Agent/main.py:46-48);
+    # the saved run's own limits (first phase over at epoch 3, last phase from epoch 8) would give 0.011 and 0.01
+    assert int(rows("p3.csv")[-1][0]) >= 8 and abs(eps3[-1] - 0.015) < 1e-6
 
 
 def test_train_self_launched_two_ranks_share_one_gpu(tmp_path):

@@ -64,23 +64,37 @@ def test_abi_exports_every_declared_symbol(pkg):
     assert det(256, 16384, 1 << 20, B=0) == 0                    # nothing to do
 
 
-def test_bench_traffic_comes_only_from_a_matching_pmc_profile():
+def test_bench_traffic_comes_only_from_a_matching_pmc_profile(tmp_path, monkeypatch):
     """roofline.traffic is a committed counter measurement only for the configuration it was taken
-    with (the protocol's 64-step launches, the driver's single 20-step launch); any other run gets
-    null and the list of configurations that were profiled."""
+    with (the protocol's 64-step launches, the driver's single 20-step launch) AND for the kernel
+    sources it was taken on (a later kernel change must not report stale traffic); any
+    other run gets null and what the committed passes were taken with."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(REPO, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     cfg = {"boards": 1048576, "steps_per_launch": 64, "cap_log2": 32, "board_size": 4, "eps": 0.95, "strict_td": False}
+    sha = bench.kernel_sources_sha16()
+    assert len(sha) == 16 and sha == bench.kernel_sources_sha16()
+    files = []
+    for name, S, val, h in (("a.json", 64, 181.0, sha), ("b.json", 20, 194.0, sha), ("c.json", 16, 200.0, "0" * 16)):
+        f = tmp_path / name
+        f.write_text(json.dumps({"bytes_per_env_step": val, "source": "rocprofv3 --pmc (test)",
+                                 "config": dict(cfg, steps_per_launch=S), "kernel_sources_sha16": h}))
+        files.append(str(f))
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILES", files)
     b64, src, other = bench.committed_pmc_traffic(cfg)
-    assert 150 < b64 < 220 and "rocprofv3" in src and other is None
-    b20, _, _ = bench.committed_pmc_traffic(dict(cfg, steps_per_launch=20))
-    assert 150 < b20 < 240 and b20 != b64
-    none, _, seen = bench.committed_pmc_traffic(dict(cfg, steps_per_launch=16))
-    assert none is None and len(seen) == 2
+    assert b64 == 181.0 and "rocprofv3" in src and other is None
+    assert bench.committed_pmc_traffic(dict(cfg, steps_per_launch=20))[0] == 194.0
+    none, _, seen = bench.committed_pmc_traffic(dict(cfg, steps_per_launch=16))       # profiled on other sources
+    assert none is None and len(seen) == 3 and seen[2]["kernel_sources_sha16"] == "0" * 16
     assert bench.committed_pmc_traffic(dict(cfg, board_size=5))[0] is None
+    # whatever is committed under profiles/ says which sources it was taken on
+    monkeypatch.undo()
+    for path in bench.PMC_TRAFFIC_FILES:
+        if os.path.exists(path):
+            assert len(json.load(open(path))["kernel_sources_sha16"]) == 16, path
 
 
 def test_header_structs_match_numpy_layout(pkg):
@@ -323,6 +337,54 @@ def test_rank_launcher_env_relay_and_failure(tmp_path):
     rc = L.launch_ranks([sys.executable, "-c", "import time; time.sleep(30)"], 2,
                         stdout=io.StringIO(), timeout=1.0)
     assert rc == 124
+
+
+def test_rank_launcher_never_orphans_its_ranks(tmp_path):
+    """a launcher that is itself terminated (a test's subprocess timeout, a scheduler) or
+    killed outright must not leave ranks behind holding a GPU.  SIGTERM: the handler stops the ranks
+    and the launcher exits 128 + 15; SIGKILL: the kernel delivers SIGTERM to the ranks
+    (PR_SET_PDEATHSIG)."""
+    import signal
+    import time
+
+    rank_py = tmp_path / "rank.py"
+    rank_py.write_text("import os, sys, time\n"
+                       "open(os.path.join(sys.argv[1], 'pid' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                       "time.sleep(120)\n")
+    parent_py = tmp_path / "parent.py"
+    parent_py.write_text(
+        "import importlib.util, sys\n"
+        f"spec = importlib.util.spec_from_file_location('l', {os.path.join(REPO, '2048_q-learning_amd', 'launch.py')!r})\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        f"raise SystemExit(m.launch_ranks([sys.executable, {str(rank_py)!r}, sys.argv[1]], 2, timeout=100))\n")
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        # a zombie of an already reaped parent is gone for our purposes
+        try:
+            return open(f"/proc/{pid}/stat").read().split(")")[1].split()[0] != "Z"
+        except OSError:
+            return False
+
+    for sig, want in ((signal.SIGTERM, 128 + 15), (signal.SIGKILL, -9)):
+        d = tmp_path / f"run{int(sig)}"
+        d.mkdir()
+        p = subprocess.Popen([sys.executable, str(parent_py), str(d)])
+        t_end = time.monotonic() + 30
+        while time.monotonic() < t_end and not (os.path.exists(d / "pid0") and os.path.exists(d / "pid1")):
+            time.sleep(0.05)
+        time.sleep(0.2)
+        pids = [int(open(d / f"pid{r}").read()) for r in range(2)]
+        assert all(alive(x) for x in pids)
+        p.send_signal(sig)
+        assert p.wait(timeout=20) == want
+        t_end = time.monotonic() + 10
+        while time.monotonic() < t_end and any(alive(x) for x in pids):
+            time.sleep(0.05)
+        assert not any(alive(x) for x in pids), f"ranks survived their launcher ({sig})"
 
 
 def test_bench_self_launches_its_ranks_and_propagates_failure():

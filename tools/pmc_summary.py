@@ -59,7 +59,13 @@ if bench and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
         read_bytes = 2.0 * summary["FETCH_SIZE"] * 1024.0
         read_how = "2 x FETCH_SIZE (128-B requests tallied at 64 B)"
     write_bytes = summary["WRITE_SIZE"] * 1024.0
-    out = {"bytes_per_env_step": read_bytes + write_bytes,
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2048_q-learning_amd", "csrc")
+    sha = hashlib.sha256()
+    for name in ("q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc"):   # = bench.KERNEL_SOURCES
+        sha.update(open(os.path.join(csrc, name), "rb").read())
+    out = {"kernel_sources_sha16": sha.hexdigest()[:16],        # bench.py reports this traffic only for these sources
+           "bytes_per_env_step": read_bytes + write_bytes,
            "read_bytes_per_env_step": read_bytes, "write_bytes_per_env_step": write_bytes,
            "fetch_size_bytes_per_env_step_uncorrected": summary["FETCH_SIZE"] * 1024.0,
            "requests_per_env_step": {k: v for k, v in summary.items() if k.startswith("TCC_")},

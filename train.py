@@ -70,7 +70,14 @@ def parse_args(argv=None):
     p.add_argument("--save", default="", help="write the trained learner (Q-table rows, epsilon schedule, counters) "
                    "to this file when training ends -- the models/ directory of the reference's README; "
                    "evaluate.py and --resume read it")
-    p.add_argument("--resume", default="", help="continue from a file written by --save (same agent arguments)")
+    p.add_argument("--resume", default="", help="continue from a file written by --save (same agent arguments): "
+                   "the table, the statistics, the epoch counter, epsilon where the saved run left it (the "
+                   "schedule's phase limits are rebuilt from this run's --episodes) and, when the batch has "
+                   "the saved shape, the boards -- save at epoch k + resume to N trains what N epochs train")
+    p.add_argument("--launch-timeout", type=float, default=86400.0,
+                   help="self-launched ranks (--gpus N > 1 outside torchrun) are stopped after this many seconds")
+    p.add_argument("--stop-epoch", type=int, default=0, help="stop (and --save) once this many epochs of the "
+                   "--episodes schedule are done; 0 = run to the end")
     p.add_argument("--summary", default="", help="after the run, write the per-episode log's summary row "
                    "(layout of the reference's plots/summary_statistics_cleaned.csv) to this CSV")
     return p.parse_args(argv)
@@ -92,14 +99,19 @@ def train_single(args, pkg):
                                exploration_rate=args.epsilon, exploration_min=args.epsilon_min,
                                capacity_log2=args.capacity_log2 or 22, device=args.device,
                                seed=args.seed)
+    first_episode = 0
     if args.resume:
-        agent._b.load_state_dict(_load(args.resume, 0))
+        sd = _load(args.resume, 0)
+        agent._b.load_state_dict(sd)
+        first_episode = _resume_schedule(agent._b, sd, args, 1)
     log_file = args.log                                                                # :71
     with open(log_file, mode="w", newline="") as file:                                 # :74-76
         csv.writer(file).writerow(["Episode", "Action", "Q-Values", "Reward", "Total-Reward", "Max Value"])
     max_number_in_train = 0
     t0, steps = time.time(), 0
-    for episode in range(num_episodes):                                                # :80
+    stop = min(num_episodes, args.stop_epoch) if args.stop_epoch else num_episodes
+    agent._b.train_progress = {"epoch": stop}
+    for episode in range(first_episode, stop):                                         # :80
         state = env.reset()                                                            # :81
         state = tuple(map(tuple, state))                                               # :82
         done = False
@@ -154,9 +166,17 @@ def train_batched(args, pkg):
         raise SystemExit("--deterministic applies to the hash-table agent")
     if (args.save or args.resume) and args.agent != "hash":
         raise SystemExit("--save / --resume apply to the hash-table agent")
+    epoch0 = 0
     if args.resume:
-        agent.load_state_dict(_load(args.resume, rank))
-        env.ctr = agent.ctr                       # fresh boards, the learner's draw counter
+        sd = _load(args.resume, rank)
+        agent.load_state_dict(sd)
+        epoch0 = _resume_schedule(agent, sd, args, shard.total_envs)
+        env_sd = sd.get("env")
+        if env_sd is not None and tuple(env_sd["boards"].shape) == tuple(env.boards.shape) and \
+                env_sd["env_id0"] == shard.env_id0 and env_sd["board_size"] == args.board_size:
+            env.load_state_dict(env_sd)           # the saved games go on where they stopped
+        else:
+            env.ctr = agent.ctr                   # fresh boards, the learner's draw counter
     if rank == 0:
         with open(args.log, mode="w", newline="") as fh:
             csv.writer(fh).writerow(["Epoch", "Episodes", "Env-Steps", "Epsilon", "Mean-Return",
@@ -170,9 +190,17 @@ def train_batched(args, pkg):
         with open(ep_path, mode="w", newline="") as fh:
             csv.writer(fh).writerow(["Episode", "Action", "Q-Values", "Reward", "Total-Reward",
                                      "Max Value", "Env"])
-    total_eps, epoch, launches, t0 = 0, 0, 0, time.time()
-    target = args.episodes * shard.total_envs
+    # a resumed run goes on from the saved statistics: `epoch` epochs are done, epsilon has been
+    # decayed that many times (Agent/main.py:109), the episode count is the restored one
+    total_eps, epoch, launches, t0 = 0, epoch0, 0, time.time()
+    if args.resume:
+        reducer.start(agent.stats_i, agent.stats_f)
+        total_eps = pkg.stats_dict(*reducer.wait())["episodes"]
+    stop_epoch = min(args.episodes, args.stop_epoch) if args.stop_epoch else args.episodes
+    target = stop_epoch * shard.total_envs
     best_tile = 0
+    agent.train_progress = {"epoch": epoch}
+    agent.train_env = env
     while total_eps < target:
         if args.deterministic:
             agent.deterministic_rollout(env, args.steps_per_launch)
@@ -194,6 +222,7 @@ def train_batched(args, pkg):
         while epoch < total_eps // shard.total_envs and epoch < args.episodes:
             agent.decay_exploration(epoch)                # Agent/main.py:109, once per epoch
             epoch += 1
+        agent.train_progress = {"epoch": epoch}
         best_tile = max(st["max_tile_hist"], default=0)
         if rank == 0:
             rate = st["steps"] / (time.time() - t0)
@@ -210,6 +239,21 @@ def train_batched(args, pkg):
     return agent
 
 
+def _resume_schedule(agent, sd, args, total_envs) -> int:
+    """After load_state_dict: how many epochs the saved run had finished, and the epsilon schedule
+    of THIS run (phase limits and decay rates from --episodes / --epsilon / --epsilon-min, as the
+    constructor computes them, Agent/main.py:25-32) carrying on from the saved epsilon -- the saved
+    limits belong to the saved run's --episodes and would pin a longer run to epsilon_min."""
+    eps_now = agent.schedule.epsilon
+    agent.schedule.__init__(args.episodes, args.epsilon, args.epsilon_min)
+    agent.schedule.epsilon = eps_now
+    agent.total_epochs = args.episodes
+    if "train" in sd:
+        return int(sd["train"]["epoch"])
+    done = int(sd["stats_i"][1])                      # Q2048_ST_EPISODES: files written before "train" existed
+    return min(args.episodes, done // max(total_envs, 1))
+
+
 def _load(path, rank):
     import torch
 
@@ -223,7 +267,12 @@ def _save(agent, path, world, rank):
 
     batched = agent._b if hasattr(agent, "_b") else agent
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    torch.save(batched.state_dict(compact=True), path if world == 1 else f"{path}.rank{rank}")
+    sd = batched.state_dict(compact=True)
+    sd["train"] = dict(getattr(batched, "train_progress", {"epoch": 0}))     # epochs finished (resume)
+    env = getattr(batched, "train_env", None)
+    if env is not None:
+        sd["env"] = env.state_dict()                                         # the games in progress
+    torch.save(sd, path if world == 1 else f"{path}.rank{rank}")
 
 
 def main(argv=None):
@@ -235,7 +284,7 @@ def main(argv=None):
         launcher = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(launcher)
         cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
-        raise SystemExit(launcher.launch_ranks(cmd, args.gpus))
+        raise SystemExit(launcher.launch_ranks(cmd, args.gpus, timeout=args.launch_timeout))
     pkg = importlib.import_module("2048_q-learning_amd")
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     single = args.num_envs == 1 and world == 1
