@@ -56,12 +56,21 @@ template <> struct Geo<5> {
   struct Key { u64 k0, k1; };
 };
 
-// LDS staging of one block's 5x5 boards (256 x 25 B = 400 x 16 B); empty for 4x4
+// LDS staging of 5x5 boards, PER WAVE: the 64 boards of a wave are 1600 contiguous bytes of HBM
+// (100 x 16 B, 16-byte aligned: 1600 = 100 * 16 and a block starts at a multiple of 6400), moved
+// with 16-byte accesses through the wave's own 1600-byte slice of LDS.  A wave is its own
+// synchronisation domain -- its LDS operations execute in program order -- so there is no
+// __syncthreads anywhere on this path (round 2 staged per block, with two barriers per direction,
+// and the single-step 5x5 kernel ran at 0.40 of the roofline).  Empty for 4x4.
 template <int N> struct Stage { };
-template <> struct Stage<5> { uint4 v[(kBlock * 25 + 15) / 16]; };
+template <> struct Stage<5> { uint4 v[kBlock / 64][100]; };
+__device__ __forceinline__ void wave_lds_sync() {      // this wave's LDS writes are done before its next LDS reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-// All threads of the block call these (the 5x5 path synchronises); lanes with i >= B get an
-// all-zero board and store nothing.
+// Every lane of a wave calls these together (lanes with i >= B get an all-zero board and store nothing).
 __device__ __forceinline__ Board load_board(const uint8_t* boards, int64_t i, int64_t B, Stage<4>&) {
   if (i >= B) return Board{0u, 0u, 0u, 0u};
   const uint4 v = reinterpret_cast<const uint4*>(boards)[i];
@@ -72,36 +81,42 @@ __device__ __forceinline__ void store_board(uint8_t* boards, int64_t i, int64_t 
   if (i < B) reinterpret_cast<uint4*>(boards)[i] = make_uint4(b.r0, b.r1, b.r2, b.r3);
 }
 __device__ __forceinline__ Board5 load_board(const uint8_t* boards, int64_t i, int64_t B, Stage<5>& st) {
-  const int64_t base = (int64_t)blockIdx.x * kBlock;
+  const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  const int64_t base = i - lane;                        // first env of the wave
   const int64_t left = B - base;
-  const int bytes = (int)(left < kBlock ? left : kBlock) * 25;
-  const uint8_t* src = boards + base * 25;  // base * 25 = blockIdx * 6400: 16-byte aligned
-  uint8_t* lds = reinterpret_cast<uint8_t*>(st.v);
-  for (int c = threadIdx.x; c * 16 < bytes; c += kBlock) {
-    if (c * 16 + 16 <= bytes) st.v[c] = reinterpret_cast<const uint4*>(src)[c];
-    else for (int k = c * 16; k < bytes; ++k) lds[k] = src[k];  // ragged tail of the last block
-  }
-  __syncthreads();
   Board5 b;
-  if (i < B) b = board5_from_bytes(lds + threadIdx.x * 25);
-  else clear(b);
-  __syncthreads();
+  clear(b);
+  if (left <= 0) return b;                              // the whole wave is past the batch
+  const int bytes = (int)(left < 64 ? left : 64) * 25;
+  const uint8_t* src = boards + base * 25;              // 16-byte aligned (see Stage<5>)
+  uint4* lds = st.v[w];
+  uint8_t* l8 = reinterpret_cast<uint8_t*>(lds);
+  for (int c = lane; c * 16 < bytes; c += 64) {
+    if (c * 16 + 16 <= bytes) lds[c] = reinterpret_cast<const uint4*>(src)[c];
+    else for (int k = c * 16; k < bytes; ++k) l8[k] = src[k];  // ragged tail of the batch's last wave
+  }
+  wave_lds_sync();
+  if (i < B) b = board5_from_bytes(l8 + lane * 25);
+  wave_lds_sync();                                      // the slice is written again by store_board
   return b;
 }
 __device__ __forceinline__ void store_board(uint8_t* boards, int64_t i, int64_t B, const Board5& b,
                                             Stage<5>& st) {
-  const int64_t base = (int64_t)blockIdx.x * kBlock;
+  const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  const int64_t base = i - lane;
   const int64_t left = B - base;
-  const int bytes = (int)(left < kBlock ? left : kBlock) * 25;
+  if (left <= 0) return;
+  const int bytes = (int)(left < 64 ? left : 64) * 25;
   uint8_t* dst = boards + base * 25;
-  uint8_t* lds = reinterpret_cast<uint8_t*>(st.v);
-  if (i < B) board5_to_bytes(b, lds + threadIdx.x * 25);
-  __syncthreads();
-  for (int c = threadIdx.x; c * 16 < bytes; c += kBlock) {
-    if (c * 16 + 16 <= bytes) reinterpret_cast<uint4*>(dst)[c] = st.v[c];
-    else for (int k = c * 16; k < bytes; ++k) dst[k] = lds[k];
+  uint4* lds = st.v[w];
+  uint8_t* l8 = reinterpret_cast<uint8_t*>(lds);
+  if (i < B) board5_to_bytes(b, l8 + lane * 25);
+  wave_lds_sync();
+  for (int c = lane; c * 16 < bytes; c += 64) {
+    if (c * 16 + 16 <= bytes) reinterpret_cast<uint4*>(dst)[c] = lds[c];
+    else for (int k = c * 16; k < bytes; ++k) dst[k] = l8[k];
   }
-  __syncthreads();
+  wave_lds_sync();
 }
 
 __device__ __forceinline__ Aux ld_aux(const q2048_aux* aux, int64_t i) {
@@ -445,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void k_env_init(uint8_t* boards, q2048_aux*
 
 // Masked reset: a lane whose mask byte is 0 touches nothing (a 1 Mi-board call after a step resets
 // under 1 % of the lanes: the launch reads the mask and little else).  5x5 boards move through the
-// block's LDS image, so there the whole block leaves together when none of its lanes is masked.
+// wave's LDS slice, so there a wave leaves together when none of its lanes is masked.
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_env_reset(uint8_t* boards, q2048_aux* aux,
                                                       const uint8_t* mask, int64_t B, uint64_t seed,
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void k_env_reset(uint8_t* boards, q2048_aux
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool mine = i < B && (mask == nullptr || mask[i] != 0);
   if constexpr (N == 4) { if (!mine) return; }
-  else { if (__syncthreads_or(mine ? 1 : 0) == 0) return; }
+  else { if (__ballot(mine) == 0ull) return; }          // 5x5 boards move through the wave's LDS slice
   auto b = load_board(boards, i, B, st);
   if (mine) {
     Aux a = ld_aux(aux, i);

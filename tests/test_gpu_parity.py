@@ -613,7 +613,7 @@ def test_four_call_loop_without_copies_and_row_cache(pkg, O, n):
 
     e1, a1 = mk(False); _unfused_loop(pkg, e1, a1, steps)          # clones, no cache
     e2, a2 = mk(True)
-    s = e2.reset()
+    s = e2.boards                      # what the constructor dealt (a reset() here would start episode 1)
     for _ in range(steps):
         a = a2.choose_action(s)
         before = s.clone()
