@@ -1048,8 +1048,16 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
     const uint32_t n_valid = wave_count(o.valid != 0), n_explore = wave_count(explored),
                    n_done = wave_count(o.done != 0), n_ins = wave_count(ins_s) + wave_count(ins_n),
                    n_drop = wave_count(dropped), n_active = wave_count(true);
-    atomicAdd(&bs.f[Q2048_SF_REWARD], (double)o.reward);
+    double wave_reward = (double)o.reward;             // one LDS atomic per wave, not 64 on one address
+    const bool full_wave = __ballot(true) == ~0ull;    // (the batch's ragged last wave adds lane by lane)
+    if (full_wave) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) wave_reward += __shfl_xor(wave_reward, d);
+    } else {
+      atomicAdd(&bs.f[Q2048_SF_REWARD], wave_reward);
+    }
     if (wave_leader()) {
+      if (full_wave) atomicAdd(&bs.f[Q2048_SF_REWARD], wave_reward);
       atomicAdd(&bs.i[Q2048_ST_STEPS], (u64)n_active);
       atomicAdd(&bs.i[Q2048_ST_VALID], (u64)n_valid);
       atomicAdd(&bs.i[Q2048_ST_EXPLORE], (u64)n_explore);

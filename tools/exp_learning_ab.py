@@ -28,6 +28,8 @@ p.add_argument("--num-envs", type=int, default=4096)
 p.add_argument("--episodes", type=int, default=50)
 p.add_argument("--seeds", type=int, default=3)
 p.add_argument("--modes", default="store/64,store/1,sc1,cas,det")
+p.add_argument("--capacity-log2", type=int, default=27)
+p.add_argument("--last", type=int, default=10, help="epochs at the end of the run that are summarised")
 args = p.parse_args()
 dev = torch.device("cuda:0")
 B, E = args.num_envs, args.episodes
@@ -38,7 +40,7 @@ for mode in args.modes.split(","):
     for seed in range(args.seeds):
         env = pkg.BatchedGame2048Env(B, seed=seed, device=dev)
         agent = pkg.BatchedQLearningAgent(E, learning_rate=0.1, discount_factor=0.99, exploration_rate=0.95,
-                                          capacity_log2=27, seed=seed, device=dev,
+                                          capacity_log2=args.capacity_log2, seed=seed, device=dev,
                                           strict_td=cfg.get("strict", False), placement="plain")
         agent.experiment_bits = cfg.get("bits", 0)
         S, t0 = cfg["S"], time.time()
@@ -65,7 +67,7 @@ for mode in args.modes.split(","):
                 agent.decay_exploration(epoch)
                 epoch += 1
         torch.cuda.synchronize()
-        last = per_epoch[-10:]
+        last = per_epoch[-args.last:]
         n = sum(e["episodes"] for e in last)
         hist = {}
         for e in last:

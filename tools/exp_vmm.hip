@@ -4,7 +4,7 @@
 // (the first chunks, the last chunks, every (n/32)-th chunk) and times the scattered requests of
 // exp_requests.hip on each mapping.
 //   hipcc -O3 --offload-arch=gfx950 -o tools/variants/exp_vmm tools/exp_vmm.hip
-//   tools/variants/exp_vmm [chunk_mib=1024] [total_gib=256]
+//   tools/variants/exp_vmm [chunk_mib=1024] [total_gib=256] [aligned_va=0] [reserve_first=0] [table_gib=32]
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
   const size_t total = (size_t)(argc > 2 ? std::atoi(argv[2]) : 256) << 30;
   const bool aligned_va = argc > 3 && std::atoi(argv[3]) != 0;     // reserve the range chunk-aligned
   const bool reserve_first = argc > 4 && std::atoi(argv[4]) != 0;  // reserve before creating chunks
-  const size_t table_bytes = (size_t)32 << 30;
+  const size_t table_bytes = (size_t)(argc > 5 ? std::atoi(argv[5]) : 32) << 30;   // table size in GiB (a power of two)
   const uint64_t cap = table_bytes / sizeof(Slot);
   CK(hipSetDevice(0));
   hipMemAllocationProp prop = {};
@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
   void* va = nullptr;
   if (reserve_first) CK(hipMemAddressReserve(&va, table_bytes, aligned_va ? chunk : 0, nullptr, 0));
   for (size_t i = 0; i < n; ++i) CK(hipMemCreate(&h[i], chunk, &prop, 0));
-  std::printf("created %zu chunks (aligned_va %d, reserve_first %d)\n", n, (int)aligned_va, (int)reserve_first);
+  std::printf("created %zu chunks (aligned_va %d, reserve_first %d), table %zu GiB = %zu chunks\n", n, (int)aligned_va, (int)reserve_first, table_bytes >> 30, per_table);
   if (!reserve_first) CK(hipMemAddressReserve(&va, table_bytes, aligned_va ? chunk : 0, nullptr, 0));
   std::printf("va %p\n", va);
   hipMemAccessDesc acc = {};
@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
       {"first chunks (consecutive)", 0, 1},
       {"first chunks, shuffled order", 0, 0},
       {"last chunks (consecutive)", n - per_table, 1},
-      {"every (n/32)-th chunk (spread)", 0, n / per_table},
+      {"every (n/per_table)-th chunk (spread)", 0, n / per_table},
       {"first chunks again", 0, 1}};
   for (auto& m : maps) {
     for (size_t k = 0; k < per_table; ++k)
