@@ -8,6 +8,7 @@ throughput entry point (whole loop body of Agent/main.py:91-101 in one launch).
 `QLearningAgent` is the one-state adapter with the reference's Python types."""
 from __future__ import annotations
 
+import ctypes as C
 import weakref
 
 import numpy as np
@@ -107,32 +108,62 @@ def _probe_us(table: torch.Tensor, capacity_log2: int, device: torch.device) -> 
     return e0.elapsed_time(e1) * 1e3 / (2 * steps)
 
 
+class _ChunkedTable:
+    """Owner of one q2048_table_alloc allocation (a table mapped from 2 MiB physical chunks),
+    handed to torch through __cuda_array_interface__: the tensor keeps this object alive, and the
+    memory goes back to the device when the last reference is dropped."""
+
+    def __init__(self, capacity_log2: int, device: torch.device, chunk_bytes: int = 0):
+        ptr = C.c_void_p()
+        with torch.cuda.device(device):
+            N.check(N.lib().q2048_table_alloc(capacity_log2, chunk_bytes, C.byref(ptr)), "q2048_table_alloc")
+        self.ptr = int(ptr.value)
+        self.__cuda_array_interface__ = {"shape": (1 << capacity_log2, N.SIZEOF_SLOT), "typestr": "|u1",
+                                         "data": (self.ptr, False), "version": 2, "strides": None}
+        self._finalizer = weakref.finalize(self, _ChunkedTable._free, self.ptr)
+
+    @staticmethod
+    def _free(ptr: int) -> None:
+        try:
+            N.lib().q2048_table_free(ptr)
+        except Exception:                       # interpreter shutdown: the process's memory goes anyway
+            pass
+
+    def tensor(self, device: torch.device) -> torch.Tensor:
+        t = torch.as_tensor(self, device=device)
+        if t.data_ptr() != self.ptr or t.dtype != torch.uint8:
+            raise RuntimeError("torch did not adopt the chunked table in place")
+        return t
+
+
 def place_table(capacity_log2: int, device: torch.device, placement="auto"):
     """Allocate the zeroed table where scattered writes run fast.
 
-    Where in device memory a multi-GiB table lies moves the scattered store / atomic rate of the
-    rollout by ~20 % (measured; DESIGN.md 4 "table placement": the EA->DRAM write path stalls more
-    on some placements, loads do not care, the effect belongs to the allocation and does not
-    change over time).  A fresh device hands out slow placements first and the driver offers no
-    control, so the choice is made by measurement.  `placement`:
-      "auto"   tables of 1..32 GiB: best of up to 4 candidates (never more than 3/4 of free
-               memory); smaller ones (cache-resident) and larger ones (they span the memory
-               system and measure fast wherever they lie) as "plain"
-      "plain"  torch.zeros (caching allocator -> hipMalloc): whatever the device yields
-      n (int)  allocate up to n candidates at once, time q2048_table_probe on each (~2 ms,
-               contents untouched), keep the fastest, release the others
-    Returns (table, report)."""
+    How a multi-GiB table's memory was obtained moves the scattered store / atomic rate of the
+    rollout by 15-20 % (DESIGN.md 4 "table placement"; loads do not care): a hipMalloc of 8-32 GiB
+    comes back in a slow or a fast state depending on where it lands, small ones nearly always slow,
+    while the same table mapped from 2 MiB physical chunks (q2048_table_alloc: HIP virtual-memory
+    API) measures as fast as one that spans 128 GiB, on every box so far.  `placement`:
+      "auto"    tables of 1..32 GiB: "chunks"; smaller ones (cache-resident) and larger ones (fast
+                as they come) "plain"
+      "chunks"  q2048_table_alloc: 2 MiB physical chunks mapped into one virtual range
+      "plain"   torch.zeros (caching allocator -> hipMalloc): whatever the device yields
+      n (int)   allocate up to n plain candidates at once, time q2048_table_probe on each (~2 ms,
+                contents untouched), keep the fastest, release the others
+    Returns (table, report); report["probe_us"] is the probe's time on the table that was kept."""
     shape = (1 << capacity_log2, N.SIZEOF_SLOT)
     nbytes = N.SIZEOF_SLOT << capacity_log2
     if placement == "auto":
-        free, _ = torch.cuda.mem_get_info(device)
-        n = min(4, int(0.75 * free) // nbytes) if (1 << 30) <= nbytes <= (32 << 30) else 1
-        placement = "plain" if n < 2 else n
+        placement = "chunks" if (1 << 30) <= nbytes <= (32 << 30) else "plain"
     if placement == "plain":
         return torch.zeros(shape, dtype=torch.uint8, device=device), {"mode": "plain"}
+    if placement == "chunks":
+        table = _ChunkedTable(capacity_log2, device).tensor(device)
+        return table, {"mode": "chunks", "chunk_bytes": 2 << 20,
+                       "probe_us": round(_probe_us(table, capacity_log2, device), 2)}
     candidates = int(placement)
     if candidates < 1:
-        raise ValueError("placement must be 'auto', 'plain' or a candidate count >= 1")
+        raise ValueError("placement must be 'auto', 'chunks', 'plain' or a candidate count >= 1")
     tables, times = [], []
     for _ in range(candidates):
         try:
@@ -171,8 +202,8 @@ class BatchedQLearningAgent:
                     (stats['drops'], status TABLE_FULL) -- never an exception.
     independent     every env owns private rows (keys salted with its global id): B independent
                     learners in one table, exactly B reference agents side by side.
-    placement       how the table is allocated (`place_table`): "auto", "plain" or a count of
-                    candidate allocations to probe.  `self.placement` is the report.
+    placement       how the table is allocated (`place_table`): "auto", "chunks", "plain" or a count
+                    of candidate allocations to probe.  `self.placement` is the report.
     strict_td       update Q[s][a] with a compare-and-swap loop (concurrent updates of one entry
                     serialise) instead of one store (last writer wins).  Same result whenever
                     no two lanes share (s, a); several times slower when many lanes do.

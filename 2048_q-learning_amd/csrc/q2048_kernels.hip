@@ -15,6 +15,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 
 #include "q2048.h"
 #include "q2048_core5.hpp"
@@ -1712,6 +1716,7 @@ const char* q2048_strerror(int code) {
     case Q2048_ERR_LAUNCH: return "HIP launch failed";
     case Q2048_ERR_RANGE: return "scalar out of range (eps in [0,1], lr and gamma finite)";
     case Q2048_ERR_FLAGS: return "flag bits this entry point does not take";
+    case Q2048_ERR_ALLOC: return "device memory could not be reserved, created or mapped";
     default: return "unknown error";
   }
 }
@@ -2129,6 +2134,80 @@ int q2048_table_probe(q2048_slot* table, int cap_log2, int64_t lanes, int steps,
   hipLaunchKernelGGL(k_table_probe, dim3(grid_for(lanes)), dim3(kBlock), 0, (hipStream_t)stream, table,
                      (1ull << cap_log2) - 1ull, lanes, steps, seed, 0u);
   return launch_status();
+}
+
+// Table allocation from small physical chunks (HIP virtual-memory API).  The only entry points that
+// allocate; everything else works on caller-owned memory, wherever it came from.
+namespace {
+struct ChunkedTable { size_t bytes, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+std::mutex g_tables_mutex;
+std::map<void*, ChunkedTable> g_tables;
+void release_chunks(void* va, ChunkedTable& t, size_t mapped) {
+  if (mapped) (void)hipMemUnmap(va, mapped * t.chunk);
+  for (auto& h : t.handles) (void)hipMemRelease(h);
+  if (va) (void)hipMemAddressFree(va, t.bytes);
+}
+}  // namespace
+
+int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot** table_out) {
+  if (table_out == nullptr) return Q2048_ERR_NULL;
+  *table_out = nullptr;
+  if (cap_log2 < 4 || cap_log2 > 40) return Q2048_ERR_SIZE;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return Q2048_ERR_LAUNCH;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0)
+    return Q2048_ERR_ALLOC;
+  ChunkedTable t;
+  t.chunk = chunk_bytes ? chunk_bytes : ((size_t)2 << 20);
+  if (t.chunk % gran != 0) return Q2048_ERR_SIZE;
+  const size_t want = sizeof(q2048_slot) << cap_log2;
+  t.bytes = (want + t.chunk - 1) / t.chunk * t.chunk;
+  void* va = nullptr;
+  if (hipMemAddressReserve(&va, t.bytes, t.chunk, nullptr, 0) != hipSuccess) return Q2048_ERR_ALLOC;
+  const size_t n = t.bytes / t.chunk;
+  t.handles.reserve(n);
+  size_t mapped = 0;
+  for (size_t k = 0; k < n; ++k) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, t.chunk, &prop, 0) != hipSuccess) { release_chunks(va, t, mapped); return Q2048_ERR_ALLOC; }
+    t.handles.push_back(h);
+    if (hipMemMap(static_cast<char*>(va) + k * t.chunk, t.chunk, 0, h, 0) != hipSuccess) {
+      release_chunks(va, t, mapped);
+      return Q2048_ERR_ALLOC;
+    }
+    ++mapped;
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if (hipMemSetAccess(va, t.bytes, &acc, 1) != hipSuccess || hipMemset(va, 0, t.bytes) != hipSuccess) {
+    release_chunks(va, t, mapped);
+    return Q2048_ERR_ALLOC;
+  }
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
+  g_tables.emplace(va, std::move(t));
+  *table_out = static_cast<q2048_slot*>(va);
+  return Q2048_OK;
+}
+
+int q2048_table_free(q2048_slot* table) {
+  if (table == nullptr) return Q2048_OK;
+  ChunkedTable t;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    auto it = g_tables.find(table);
+    if (it == g_tables.end()) return Q2048_ERR_NULL;      // not one of q2048_table_alloc's
+    t = std::move(it->second);
+    g_tables.erase(it);
+  }
+  if (hipDeviceSynchronize() != hipSuccess) return Q2048_ERR_LAUNCH;
+  release_chunks(table, t, t.handles.size());
+  return Q2048_OK;
 }
 
 int q2048_table_count(const q2048_slot* table, int cap_log2, int64_t* count, void* stream) {

