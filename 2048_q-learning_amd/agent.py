@@ -182,15 +182,19 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto"):
                    "probe_us": [round(x, 2) for x in times], "chosen": chosen}
 
 
-def auto_capacity_log2(min_rows: int, device, max_log2: int = 33, memory_fraction: float = 0.5) -> int:
-    """Table size for a run that will create up to `min_rows` rows: load factor <= 0.5, and
-    beyond that as much of the device as `memory_fraction` of its free memory allows (a power of
-    two of 32-B slots).  A 64+ GiB table spans the whole memory system -- scattered writes run at
-    the fast rate wherever it lies -- and probes stay one slot long."""
+def auto_capacity_log2(min_rows: int, device, max_log2: int = 33, floor_log2: int = 30,
+                       memory_fraction: float = 0.25) -> int:
+    """Table size for a run that will create up to `min_rows` rows: load factor <= 0.5, and not
+    below 2^`floor_log2` slots (32 GiB) when that fits in `memory_fraction` of the free device
+    memory.  Why a floor: a 2^30-slot table mapped from 2 MiB chunks (`place_table`) runs the rollout
+    as fast as one that spans 128 GiB (0.331 against 0.327 of the roofline on the driver's bench
+    command), a 2^28-slot one 6 % slower even so -- smaller footprints take scattered atomics more
+    slowly on this memory system -- and memory is what an MI355X has plenty of.
+    Round 2 took half of the device (2^32 slots) for the same speed."""
     need = max(20, int(np.ceil(np.log2(2.0 * max(int(min_rows), 1)))))
     free, _ = torch.cuda.mem_get_info(torch.device(device))
     fit = int(np.floor(np.log2(max(memory_fraction * free / N.SIZEOF_SLOT, 2.0))))
-    return min(max(need, min(fit, max_log2)), 40)
+    return min(max(need, min(fit, floor_log2, max_log2)), 40)
 
 
 class BatchedQLearningAgent:

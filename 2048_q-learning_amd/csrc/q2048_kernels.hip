@@ -5,8 +5,9 @@
 //                          5x5: 25 B per board, unpadded; a block moves its 6400 contiguous
 //                          bytes with 16-byte accesses through LDS and each lane picks its 25
 //   aux     16 B per env   one dwordx4 per lane
-//   table   32 B slots     {u64 key, f32 q[4], u64 key_hi}; random access, one 64-B line per
-//                          probe; linear probing keeps collisions in the same line
+//   table   32 B slots     {u64 key, f32 q[4], u64 key_hi}; random access, one 128-B line (four
+//                          slots) per probe; the probe sequence visits the line's other three
+//                          slots before it moves to the next line (`Seq`)
 // One board per lane.  Boards, aux and the carried Q row live in VGPRs for a whole launch;
 // per-step boolean statistics are wave ballots accumulated in SGPRs, rare per-episode
 // statistics go through LDS, and each block ends with one global atomic per statistic.

@@ -159,13 +159,17 @@ def cpu_model() -> str:
 
 def cpu_baseline(args, seconds: float) -> dict:
     """Times the CPU oracle (kind 'port') on a bounded sample of the same workload: one thread,
-    a quarter of the cores and all usable cores, each with a private Q-table per thread."""
+    16, 32, a quarter of the cores and all usable cores, each with a private Q-table per thread; the
+    best is reported, all are listed.  (More threads is not more throughput here: on the GPU box's
+    2 x 64-core host the total peaks at 16-32 threads -- random accesses into tens of MiB of table per
+    thread -- and falls to less than half on all 256 hardware threads, profiles/r03_cpu_mt.jsonl.)"""
     from oracle import oracle as O
 
     O.lib()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     runs = {}
-    for T in sorted({1, max(1, cores // 4), cores}):
+    per = max(seconds / 5.0, 0.2)
+    for T in sorted({1, min(16, cores), min(32, cores), max(1, cores // 4), cores}):
         B, steps = 16384 * T, 24
         envs = O.envs_init(B, 4, args.seed, 0)
         agents = [O.Agent(1000, 4, args.alpha, args.gamma, args.eps) for _ in range(T)]
@@ -173,7 +177,7 @@ def cpu_baseline(args, seconds: float) -> dict:
             a.reserve(16384 * 64)      # rows one thread can create in this sample (no rehash)
         O.rollout_mt(envs, agents, 8, args.seed, 0, 0)                 # warm-up
         done, t0 = 0, time.perf_counter()
-        budget = seconds / 3
+        budget = per
         ctr = 8
         while True:
             O.rollout_mt(envs, agents, steps, args.seed, 0, ctr)
@@ -311,8 +315,8 @@ def run_rank(args):
     shard = pkg.weak_shard(B, world, rank)
     S = max(1, min(args.steps_per_launch, args.steps))
     learn_steps = args.warmup + args.repeats * args.steps
-    # every step may create a row: load <= 0.5 at the end of the run, and beyond that half of the
-    # device's free memory (a table that spans the memory system: DESIGN.md 4 "table placement")
+    # every step may create a row: load <= 0.5 at the end of the run, and at least 2^30 slots (32 GiB,
+    # mapped from 2 MiB chunks: as fast as a table spanning 128 GiB, DESIGN.md 4 "table placement")
     cap_log2 = args.cap_log2 or pkg.auto_capacity_log2(B * max(learn_steps, 1), dev, max_log2=32)
     if args.agent == "hash" and args.cap_log2:
         # a table given by hand must still end the run below load ~0.6 (0.75 new rows per board-step

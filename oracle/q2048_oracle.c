@@ -640,9 +640,11 @@ void orc_rollout_sync(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t st
 }
 
 typedef struct {
+  char pad0[128]; /* a thread bumps si / sf every step: keep neighbours' counters off its cache lines */
   orc_env_t *envs; int64_t B; orc_agent_t *agent; int64_t steps;
   uint64_t seed, env_id0; uint32_t ctr0;
   int64_t si[ORC_ST_NI]; double sf[ORC_SF_NF];
+  char pad1[128];
 } orc_job_t;
 
 static void *orc_job_run(void *p) {
