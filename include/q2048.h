@@ -328,7 +328,9 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  * profiles/r03_requests/vmm_*_8GiB.txt; loads do not care) -- as fast as a table that spans 128 GiB.
  * q2048_table_alloc reserves, creates, maps and zero-fills 2^cap_log2 slots (chunk_bytes = 0: 2 MiB;
  * else a multiple of the allocation granularity) on the current device and is host-synchronous;
- * q2048_table_free unmaps and releases (synchronises the device first).  Both are thread-safe. */
+ * q2048_table_free unmaps the chunks and releases their physical memory (it synchronises the device
+ * first); the table's virtual address range stays reserved until the process ends -- a re-used
+ * range was seen to serve stale translations on ROCm 7.2.  Both are thread-safe. */
 int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot **table_out);
 int q2048_table_free(q2048_slot *table);
 
