@@ -358,9 +358,9 @@ __device__ __forceinline__ int64_t claim_resolve(q2048_slot* table, u64 mask, co
 //          (s, a) at the same time the last writer wins (never a torn value).
 //   CAS (Q2048_FLAG_TD_CAS)  compare-and-swap loop: a failed swap returns the live value and
 //          the update is recomputed from it, so concurrent updates of one (s, a) serialise -- for
-//          up to kMaxCas attempts; an entry contended beyond that takes the update as an atomic
-//          add of (new - last seen): the sample is never lost, only its weight is taken against a
-//          value a few hundred nanoseconds old.  Those fall-backs are counted (Q2048_ST_CAS_FALLBACK).
+//          up to kMaxCas attempts; an entry contended beyond that takes the update as a plain
+//          store, as the default mode would (last writer wins), and the event is counted
+//          (Q2048_ST_CAS_FALLBACK): strict mode's guarantee is bounded, and a run can tell by how much.
 //   NONE   nothing is written (Q2048_FLAG_NO_LEARN).
 //   The other modes are measurement variants (Q2048_EXPERIMENTS builds only).
 enum : uint32_t { kTdStorePlain = 0, kTdCas = 1, kTdStoreSc1 = 2, kTdStoreNt = 3, kTdNone = 4,
@@ -392,10 +392,12 @@ __device__ __forceinline__ float td_update(q2048_slot* slot, int a, float guess,
   // kMaxCas lost races in a row: the entry is being rewritten every few hundred nanoseconds.
   // Spinning on costs far more than exactness here is worth -- unbounded, a few such entries (the
   // opening states at low epsilon) stretched every wave's step 4x (181 -> 71 us per 1 Mi boards at
-  // eps = 0.01, profiles/r02_strict_td_retries.jsonl) -- so the update goes in as an atomic add of
-  // its increment against the last value seen: nothing is lost, and the fall-back is counted
+  // eps = 0.01, profiles/r02_strict_td_retries.jsonl) -- so the update is written as the default
+  // mode writes it, and counted.  (An atomic add of the increment instead -- no sample lost -- was
+  // tried in round 3: the same hot entries then serialise at the memory side, 84 -> 267 us per step
+  // from reset at eps = 0.01, profiles/r03_batch_sweep.jsonl history.)
   ++ctrs.fallbacks;
-  atomicAdd(&slot->q[a], nq - bits_f32(expect));
+  *addr = f32_bits(nq);
   return nq;
 }
 // Deferred TD writes: while a lane stays in one state (invalid moves: the board did not change)

@@ -102,7 +102,8 @@ def parse_args(argv=None):
                    help="table allocation (agent.place_table): auto | chunks (2 MiB physical chunks, "
                         "q2048_table_alloc) | plain (hipMalloc) | N (best of N probed candidates)")
     p.add_argument("--strict-td", action="store_true",
-                   help="TD write by compare-and-swap loop (Q2048_FLAG_TD_CAS) instead of one store")
+                   help="TD write by compare-and-swap loop (Q2048_FLAG_TD_CAS) instead of one store; bounded: "
+                        "after 16 lost races an update is stored plainly and counted (stats.cas_fallbacks)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 = skip")
     p.add_argument("--experiment-bits", type=lambda v: int(v, 0), default=0,
                    help="unstable tuning bits OR-ed into the fused kernel's flags (ablations; not ABI)")
@@ -400,7 +401,7 @@ def run_rank(args):
                   "drops": st["drops"],
                   "table_rows_per_gpu": m["table_rows"], "claim_timeouts": pkg._native.claim_timeouts(),
                   "table_load_factor": None if m["table_rows"] is None else m["table_rows"] / float(1 << cap_log2),
-                  "cas_retries": st["cas_retries"], "status": m["status"],
+                  "cas_retries": st["cas_retries"], "cas_fallbacks": st["cas_fallbacks"], "status": m["status"],
                   "episodes_per_env_before_timing": m["prep_episodes_per_env"],
                   "max_tile_hist": {str(k): v for k, v in st["max_tile_hist"].items()}},
         "kernel_ms_total": sum(r["kernel_ms"] for r in m["regions"]),

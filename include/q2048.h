@@ -67,9 +67,9 @@ extern "C" {
 #define Q2048_FLAG_TD_CAS 4u      /* TD update by a compare-and-swap loop: concurrent updates of one
                                      (s, a) serialise instead of "last writer wins" -- for up to 16
                                      attempts per update; an entry contended beyond that takes the
-                                     update as an atomic add of its increment (nothing is lost, the
-                                     weight is taken against a slightly stale value) and the event
-                                     is counted in Q2048_ST_CAS_FALLBACK.  Identical to the default
+                                     update as a plain store, like the default mode, and the event
+                                     is counted in Q2048_ST_CAS_FALLBACK: the guarantee is bounded,
+                                     and the statistics say by how much.  Identical to the default
                                      whenever no two lanes share (s, a) */
 
 #define Q2048_FLAG_ENV_DQN 8u      /* env step = the DQN path's env instead of Game2048_env.step:
@@ -142,8 +142,8 @@ enum {
   Q2048_ST_EXPLORE = 6,  /* epsilon branch taken */
   Q2048_ST_CAS_RETRY = 7,/* TD compare-and-swap retries (same (s,a) updated concurrently) */
   Q2048_ST_HIST0 = 8,    /* max-tile histogram of finished episodes, log2 0..22 (saturating) */
-  Q2048_ST_CAS_FALLBACK = 31, /* Q2048_FLAG_TD_CAS updates that lost 16 races in a row and went in
-                                 as an atomic add of their increment instead */
+  Q2048_ST_CAS_FALLBACK = 31, /* Q2048_FLAG_TD_CAS updates that lost 16 races in a row and were
+                                 written as a plain store instead */
   Q2048_NSTAT_I = 32
 };
 enum { Q2048_SF_RETURN = 0, Q2048_SF_RETURN_SQ = 1, Q2048_SF_REWARD = 2, Q2048_NSTAT_F = 4 };

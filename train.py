@@ -48,7 +48,8 @@ def parse_args(argv=None):
     p.add_argument("--device", default="cuda")
     p.add_argument("--steps-per-launch", type=int, default=64)
     p.add_argument("--capacity-log2", type=int, default=0, help="Q-table slots = 2^n (0 = auto)")
-    p.add_argument("--strict-td", action="store_true", help="compare-and-swap TD writes")
+    p.add_argument("--strict-td", action="store_true", help="compare-and-swap TD writes (bounded: after 16 lost "
+                   "races an update is stored plainly and counted in the statistics)")
     p.add_argument("--deterministic", action="store_true",
                    help="batched mode: reproducible two-phase steps (slower; see deterministic_rollout)")
     p.add_argument("--agent", choices=["hash", "row-tuple"], default="hash",
