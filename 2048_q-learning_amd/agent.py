@@ -154,7 +154,13 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto"):
     shape = (1 << capacity_log2, N.SIZEOF_SLOT)
     nbytes = N.SIZEOF_SLOT << capacity_log2
     if placement == "auto":
-        placement = "chunks" if (1 << 30) <= nbytes <= (32 << 30) else "plain"
+        if (1 << 30) <= nbytes <= (32 << 30):
+            try:
+                return place_table(capacity_log2, device, "chunks")
+            except (N.NativeError, RuntimeError) as exc:      # no virtual-memory API on this stack, or no room:
+                table = torch.zeros(shape, dtype=torch.uint8, device=device)   # the slower kind of table
+                return table, {"mode": "plain", "chunks_failed": str(exc)}
+        placement = "plain"
     if placement == "plain":
         return torch.zeros(shape, dtype=torch.uint8, device=device), {"mode": "plain"}
     if placement == "chunks":
