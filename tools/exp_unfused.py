@@ -11,12 +11,16 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
+TD_BITS = int(os.environ.get("UNFUSED_TD_BITS", "0"), 0)      # measurement build: write mode of k_q_update (2 << 8 = sc1)
+if TD_BITS:
+    pkg._native.use_experiments_build()
 dev = torch.device("cuda:0")
 for B in (1 << 20, 1 << 16):
     env = pkg.BatchedGame2048Env(B, seed=0, device=dev)
     agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99, exploration_rate=0.95,
                                       capacity_log2=32 if B == 1 << 20 else 28, seed=0, device=dev, placement="plain")
     agent.fused_rollout(env, 256, play_only=True)
+    agent.flags |= TD_BITS
 
     def loop(steps):                      # Agent/main.py:92-100, :81 in batched form
         s = env.boards
@@ -35,6 +39,7 @@ for B in (1 << 20, 1 << 16):
     print(json.dumps({"api": "4-call (choose, step, update, reset)", "B": B, "steps": steps,
                       "us_per_step": round(ms * 1e3 / steps, 1), "env_steps_per_s": B * steps / ms * 1e3}), flush=True)
     agent.ctr = env.ctr
+    agent.flags &= 0xff
     e0.record(); agent.fused_rollout(env, steps); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     print(json.dumps({"api": "fused_rollout", "B": B, "steps": steps, "us_per_step": round(ms * 1e3 / steps, 1),

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Confidence run (not part of the test suite): the independent-lane parity check of
 tests/test_gpu_parity.py over more seeds, both geometries, every env profile, deferred writes on and
-off, random launch splits.  Boards and aux bit-exact, every Q row within rtol 1e-5."""
+off, random launch splits, and -- for a third of the cases -- the 4-call API (choose_action, step into
+the other board buffer, update_q_value with the row cache, reset(done)) instead of the fused rollout,
+switching between the two in mid-run.  Boards and aux bit-exact, every Q row within rtol 1e-5."""
 import importlib
 import os
 import sys
@@ -37,10 +39,19 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
                                       capacity_log2=19, seed=seed, env_id0=id0, device=dev, independent=True,
                                       board_size=n, strict_td=strict)
     agent.experiment_bits = bits
+    four_call = bool(rng.integers(0, 3) == 0)
     left = steps
     while left > 0:
         k = int(min(left, rng.integers(1, 200)))
-        agent.fused_rollout(env, k)
+        if four_call and rng.integers(0, 2):
+            state = env.boards
+            for _ in range(k):
+                a = agent.choose_action(state)
+                nxt, r, d, _ = env.step(a)
+                agent.update_q_value(state, a, r, nxt, d)
+                state = env.reset(d)
+        else:
+            agent.fused_rollout(env, k)
         left -= k
     assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :n * n]), (trial, "boards")
     f = env.aux_fields()
@@ -54,5 +65,5 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     assert agent.table_size() == sum(len(a) for a in agents) and agent.check_status() == 0
     cases += 1
     print(f"trial {trial}: {n}x{n} B={B} steps={steps} eps={eps} profile={profile} reset_shaping={reset_shaping} "
-          f"strict={strict} bits={bits:#x}: ok, worst relative Q error {worst:.2e}", flush=True)
+          f"strict={strict} bits={bits:#x} four_call={four_call}: ok, worst relative Q error {worst:.2e}", flush=True)
 print(f"{cases} cases passed")
