@@ -27,11 +27,13 @@ int main(int argc, char **argv) {
   uint8_t *boards; q2048_aux *aux; q2048_slot *table; int64_t *stats_i; double *stats_f; uint32_t *status;
   CHECK_HIP(hipMalloc((void **)&boards, (size_t)B * 16));
   CHECK_HIP(hipMalloc((void **)&aux, (size_t)B * sizeof(q2048_aux)));
-  CHECK_HIP(hipMalloc((void **)&table, sizeof(q2048_slot) << cap_log2));
+  /* the table: any zero-filled device memory will do (hipMalloc + hipMemset); the library's own
+   * allocator maps it from 2 MiB physical chunks, which this memory system serves 15-20 % faster
+   * under scattered writes (include/q2048.h, q2048_table_alloc) */
+  CHECK_Q(q2048_table_alloc(cap_log2, 0, &table));
   CHECK_HIP(hipMalloc((void **)&stats_i, sizeof(int64_t) * Q2048_NSTAT_I));
   CHECK_HIP(hipMalloc((void **)&stats_f, sizeof(double) * Q2048_NSTAT_F));
   CHECK_HIP(hipMalloc((void **)&status, sizeof(uint32_t)));
-  CHECK_HIP(hipMemset(table, 0, sizeof(q2048_slot) << cap_log2));   /* zero = empty table */
   CHECK_HIP(hipMemset(stats_i, 0, sizeof(int64_t) * Q2048_NSTAT_I));
   CHECK_HIP(hipMemset(stats_f, 0, sizeof(double) * Q2048_NSTAT_F));
   CHECK_HIP(hipMemset(status, 0, sizeof(uint32_t)));
@@ -59,5 +61,6 @@ int main(int argc, char **argv) {
          (long long)si[Q2048_ST_INSERTS], (long long)si[Q2048_ST_DROPS], (long long)si[Q2048_ST_EXPLORE],
          (long long)rows, st, sf[Q2048_SF_RETURN]);
   for (int c = 0; c < 16; ++c) printf("%d%s", first[c], c < 15 ? ", " : "]}\n");
+  CHECK_Q(q2048_table_free(table));
   return 0;
 }
