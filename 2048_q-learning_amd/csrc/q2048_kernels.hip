@@ -67,8 +67,8 @@ template <> struct Geo<5> {
 // synchronisation domain -- its LDS operations execute in program order -- so there is no
 // __syncthreads anywhere on this path (round 2 staged per block, with two barriers per direction,
 // and the single-step 5x5 kernel ran at 0.40 of the roofline).  Empty for 4x4.
-template <int N> struct Stage { };
-template <> struct Stage<5> { uint4 v[kBlock / 64][100]; };
+template <int N, int WAVES = kBlock / 64> struct Stage { };
+template <int WAVES> struct Stage<5, WAVES> { uint4 v[WAVES][100]; };
 __device__ __forceinline__ void wave_lds_sync() {      // this wave's LDS writes are done before its next LDS reads
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -76,16 +76,19 @@ __device__ __forceinline__ void wave_lds_sync() {      // this wave's LDS writes
 }
 
 // Every lane of a wave calls these together (lanes with i >= B get an all-zero board and store nothing).
-__device__ __forceinline__ Board load_board(const uint8_t* boards, int64_t i, int64_t B, Stage<4>&) {
+template <int WAVES>
+__device__ __forceinline__ Board load_board(const uint8_t* boards, int64_t i, int64_t B, Stage<4, WAVES>&) {
   if (i >= B) return Board{0u, 0u, 0u, 0u};
   const uint4 v = reinterpret_cast<const uint4*>(boards)[i];
   return Board{v.x, v.y, v.z, v.w};
 }
+template <int WAVES>
 __device__ __forceinline__ void store_board(uint8_t* boards, int64_t i, int64_t B, const Board& b,
-                                            Stage<4>&) {
+                                            Stage<4, WAVES>&) {
   if (i < B) reinterpret_cast<uint4*>(boards)[i] = make_uint4(b.r0, b.r1, b.r2, b.r3);
 }
-__device__ __forceinline__ Board5 load_board(const uint8_t* boards, int64_t i, int64_t B, Stage<5>& st) {
+template <int WAVES>
+__device__ __forceinline__ Board5 load_board(const uint8_t* boards, int64_t i, int64_t B, Stage<5, WAVES>& st) {
   const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
   const int64_t base = i - lane;                        // first env of the wave
   const int64_t left = B - base;
@@ -105,8 +108,9 @@ __device__ __forceinline__ Board5 load_board(const uint8_t* boards, int64_t i, i
   wave_lds_sync();                                      // the slice is written again by store_board
   return b;
 }
+template <int WAVES>
 __device__ __forceinline__ void store_board(uint8_t* boards, int64_t i, int64_t B, const Board5& b,
-                                            Stage<5>& st) {
+                                            Stage<5, WAVES>& st) {
   const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
   const int64_t base = i - lane;
   const int64_t left = B - base;
@@ -442,6 +446,33 @@ __device__ __forceinline__ void stats_flush(BlockStats& s, int64_t* gi, double* 
   if (gf != nullptr && threadIdx.x < Q2048_NSTAT_F && s.f[threadIdx.x] != 0.0)
     atomicAdd(gf + threadIdx.x, s.f[threadIdx.x]);
 }
+// Striped statistics (deterministic step).  A block's flush is one global atomic per non-zero
+// statistic, and with 4096 blocks per one-step launch all of them queue on the same few addresses:
+// at 1 Mi boards that serial tail was 30 of the step's 189 us (statistics pointers NULL: 159 us,
+// tools/exp_stats_cost.py).  So phase 1 adds into one of kStatStripes copies chosen by block index
+// (64 atomics per address and launch instead of 4096), kept in the caller's workspace, and one small
+// launch at the end of the call folds the copies into the caller's vectors.
+constexpr int kStatStripes = 64;
+struct StatStripe { u64 i[Q2048_NSTAT_I]; double f[Q2048_NSTAT_F]; };
+__device__ __forceinline__ void stats_flush_striped(BlockStats& s, StatStripe* stripes) {
+  __syncthreads();
+  if (stripes == nullptr) return;
+  StatStripe& mine = stripes[blockIdx.x % kStatStripes];
+  if (threadIdx.x < Q2048_NSTAT_I && s.i[threadIdx.x] != 0ull) atomicAdd(&mine.i[threadIdx.x], s.i[threadIdx.x]);
+  if (threadIdx.x < Q2048_NSTAT_F && s.f[threadIdx.x] != 0.0) atomicAdd(&mine.f[threadIdx.x], s.f[threadIdx.x]);
+}
+__global__ __launch_bounds__(64) void k_stats_fold(const StatStripe* stripes, int64_t* gi, double* gf) {
+  const int t = (int)threadIdx.x;
+  if (t < Q2048_NSTAT_I && gi != nullptr) {
+    u64 sum = 0ull;
+    for (int k = 0; k < kStatStripes; ++k) sum += stripes[k].i[t];
+    if (sum) atomicAdd(reinterpret_cast<u64*>(gi) + t, sum);
+  } else if (t >= Q2048_NSTAT_I && t < Q2048_NSTAT_I + Q2048_NSTAT_F && gf != nullptr) {
+    double sum = 0.0;                                     // stripes in index order: a fixed summation order
+    for (int k = 0; k < kStatStripes; ++k) sum += stripes[k].f[t - Q2048_NSTAT_I];
+    if (sum != 0.0) atomicAdd(gf + (t - Q2048_NSTAT_I), sum);
+  }
+}
 __device__ __forceinline__ void episode_stats(BlockStats& s, const Aux& a, uint32_t max_l2) {
   atomicAdd(&s.i[Q2048_ST_SCORE], (u64)(int64_t)a.score);
   atomicAdd(&s.i[Q2048_ST_HIST0 + (max_l2 > 22u ? 22u : max_l2)], 1ull);
@@ -751,17 +782,24 @@ __global__ __launch_bounds__(kBlock) void k_q_lookup(const q2048_slot* table, u6
   if (found != nullptr) found[i] = slot >= 0;
 }
 
+// Workgroups of kUpdateBlock = 1024 lanes: every block ends with one global atomic per non-zero
+// statistic, all on the same few addresses, and in a one-step launch those same-address atomics are
+// a serial tail -- 4096 blocks of 256 cost the launch 15 of its 85 us at 1 Mi boards (statistics
+// pointer NULL: 101 against 116 us per 4-call step, tools/exp_unfused.py UNFUSED_NO_STATS); a
+// quarter as many blocks, a quarter of the tail.  (The fused kernel amortises its flush over K steps:
+// no measurable cost there.)
+constexpr int kUpdateBlock = 1024;
 template <int N>
-__global__ __launch_bounds__(kBlock) void k_q_update(q2048_slot* table, u64 mask, const uint8_t* s,
+__global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u64 mask, const uint8_t* s,
                                                      const uint8_t* actions, const float* reward,
                                                      const uint8_t* s2, const uint8_t* done, int64_t B,
                                                      double lr, double gamma, uint64_t env_id0,
                                                      uint32_t flags, RowCache<N>* cache, int64_t* stats_i,
                                                      uint32_t* status) {
   __shared__ BlockStats bs;
-  __shared__ Stage<N> st;
+  __shared__ Stage<N, kUpdateBlock / 64> st;
   stats_clear(bs);
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kUpdateBlock + threadIdx.x;
   const auto b_s = load_board(s, i, B, st);
   const auto b_n = load_board(s2, i, B, st);
   if (i < B) {
@@ -999,12 +1037,13 @@ __device__ __forceinline__ Row ld_row(const q2048_slot* s) {
   const u32x4 v = ld16_agent(&s->q[0]);
   return Row{bits_f32(v.x), bits_f32(v.y), bits_f32(v.z), bits_f32(v.w)};
 }
+// 4x4: 8 waves per SIMD (64 VGPRs, 3 dwords of scratch) measures 165.0 us per 1 Mi-board step against
+// 167.9 at the unconstrained 65 VGPRs / 7 waves; 5x5 would spill 8-17 dwords for it and keeps 7
 template <int N, int ENV>
-__global__ __launch_bounds__(kBlock) void k_det_phase1(
+__global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
     uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, double* target_out,
-    uint32_t* carry, int use_carry, u64* longs, int64_t* stats_i, double* stats_f,
-    uint32_t* status) {
+    uint32_t* carry, int use_carry, u64* longs, StatStripe* stat_stripes, uint32_t* status) {
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
   stats_clear(bs);
@@ -1074,7 +1113,7 @@ __global__ __launch_bounds__(kBlock) void k_det_phase1(
     }
   }
   store_board(boards, i, B, b, st);
-  stats_flush(bs, stats_i, stats_f);
+  stats_flush_striped(bs, stat_stripes);
 }
 
 // The sort: least-significant-digit radix passes of 8 bits over (group, target) pairs, each pass a
@@ -1891,11 +1930,11 @@ int q2048_q_update_cached(q2048_slot* table, int cap_log2, const uint8_t* boards
   if (B == 0) return Q2048_OK;
   const u64 mask = (1ull << cap_log2) - 1ull;
   if (n == 4)
-    hipLaunchKernelGGL(k_q_update<4>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table, mask,
+    hipLaunchKernelGGL(k_q_update<4>, dim3((unsigned)((B + kUpdateBlock - 1) / kUpdateBlock)), dim3(kUpdateBlock), 0, (hipStream_t)stream, table, mask,
                        boards_s, actions, reward, boards_s2, done, B, lr, gamma, env_id0, flags,
                        static_cast<RowCache<4>*>(row_cache), stats_i, status);
   else
-    hipLaunchKernelGGL(k_q_update<5>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, table, mask,
+    hipLaunchKernelGGL(k_q_update<5>, dim3((unsigned)((B + kUpdateBlock - 1) / kUpdateBlock)), dim3(kUpdateBlock), 0, (hipStream_t)stream, table, mask,
                        boards_s, actions, reward, boards_s2, done, B, lr, gamma, env_id0, flags,
                        static_cast<RowCache<5>*>(row_cache), stats_i, status);
   return launch_status();
@@ -1956,7 +1995,7 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
 // workspace of q2048_det_rollout: double-buffered (group, target) pairs, the slot every env holds
 // for its next step, the list of long groups, the sort's per-tile digit counts and digit totals;
 // every part 256-byte aligned
-struct DetLayout { size_t group[2], target[2], carry, longs, cnt, total_cnt, total; int64_t tiles; };
+struct DetLayout { size_t group[2], target[2], carry, longs, cnt, total_cnt, stripes, total; int64_t tiles; };
 static int det_layout(int64_t B, int, DetLayout& L) {
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t at = 0;
@@ -1967,6 +2006,7 @@ static int det_layout(int64_t B, int, DetLayout& L) {
   L.tiles = (B + kSortTile - 1) / kSortTile;
   L.cnt = at; at += up((size_t)L.tiles * kBlock * 4);
   L.total_cnt = at; at += up((size_t)kBlock * 4);
+  L.stripes = at; at += up(sizeof(StatStripe) * kStatStripes);
   L.total = at;
   return Q2048_OK;
 }
@@ -2005,6 +2045,10 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   uint32_t* total_cnt = reinterpret_cast<uint32_t*>(ws + L.total_cnt);
   u64* longs = reinterpret_cast<u64*>(ws + L.longs);
   const hipStream_t s = (hipStream_t)stream;
+  // statistics: striped copies in the workspace, folded into the caller's vectors once per call
+  StatStripe* stripes = (stats_i != nullptr || stats_f != nullptr) ? reinterpret_cast<StatStripe*>(ws + L.stripes) : nullptr;
+  if (stripes != nullptr && hipMemsetAsync(stripes, 0, sizeof(StatStripe) * kStatStripes, s) != hipSuccess)
+    return Q2048_ERR_LAUNCH;
   const u64 mask = (1ull << cap_log2) - 1ull;
   // sort range: the 16 hash bits of the update word (comment at k_det_apply).  Experiment builds:
   // bits 8..13 of flags = k sorts by the low k hash bits only (crowded runs), 63 by the whole word
@@ -2017,7 +2061,7 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   for (int64_t t = 0; t < steps; ++t) {
     Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
                      ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), longs,
-                     stats_i, stats_f, status);
+                     stripes, status);
     int cur = 0;                                     // which buffer holds the pairs
     for (int lo = sort_lo; lo < sort_hi; lo += 8, cur ^= 1) {
       const uint32_t dmask = sort_hi - lo >= 8 ? 255u : (1u << (sort_hi - lo)) - 1u;
@@ -2034,7 +2078,9 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
                        run_mask, longs);
     if (int e = launch_status()) return e;
   }
-  return Q2048_OK;
+  if (stripes != nullptr)
+    hipLaunchKernelGGL(k_stats_fold, dim3(1), dim3(64), 0, s, stripes, stats_i, stats_f);
+  return launch_status();
 }
 
 int q2048_legal_moves(const uint8_t* boards, int64_t B, int n, uint8_t* mask_out, void* stream) {

@@ -10,7 +10,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
-pkg._native.use_experiments_build()   # the measurement build: experiment bits 8..23 of `flags`
+if os.environ.get("DET_BITS"):
+    pkg._native.use_experiments_build()   # the measurement build: experiment bits 8..23 of `flags`
 dev = torch.device("cuda:0")
 for B, steps in ((1 << 20, 96), (1 << 16, 256)):
     for mode in ("deterministic", "fused"):

@@ -30,6 +30,9 @@ for B in (1 << 20, 1 << 16):
             agent.update_q_value(s, a, r, s2, d)
             s = env.reset(d)
 
+    keep_stats = agent.stats_i
+    if os.environ.get("UNFUSED_NO_STATS"):          # how much of k_q_update is its per-block statistics atomics?
+        agent.stats_i = None
     loop(8)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,6 +42,7 @@ for B in (1 << 20, 1 << 16):
     print(json.dumps({"api": "4-call (choose, step, update, reset)", "B": B, "steps": steps,
                       "us_per_step": round(ms * 1e3 / steps, 1), "env_steps_per_s": B * steps / ms * 1e3}), flush=True)
     agent.ctr = env.ctr
+    agent.stats_i = keep_stats
     agent.flags &= 0xff
     e0.record(); agent.fused_rollout(env, steps); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
