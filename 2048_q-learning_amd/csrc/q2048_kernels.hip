@@ -804,6 +804,10 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
   const auto b_n = load_board(s2, i, B, st);
   if (i < B) {
     const int act = actions[i];
+    // every coalesced input is requested here, together: the probes below are `asm volatile` with a
+    // memory clobber, and a load left after them would wait for its own round trip behind theirs
+    const float rew = reward[i];
+    const bool is_done = done[i] != 0;
     bool ins_n = false, ins_s = false, dropped = false;
     TdCounters tdc{0u, 0u};
     if (act > 3) {
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
       }
       const float max_next = max4(rn.q0, rn.q1, rn.q2, rn.q3);
       if (slot >= 0) {
-        const float nq = td_update(&table[slot], act, row_get(rs, act), reward[i], max_next, done[i] != 0,
+        const float nq = td_update(&table[slot], act, row_get(rs, act), rew, max_next, is_done,
                                    lr, gamma, tdc, td_mode_of(flags));
         if (same) row_set(rn, act, nq);                  // the row it stays on just changed (:100)
       } else {
@@ -1297,6 +1301,13 @@ __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u
   if (j >= B) return;
   const u64* w = tile + kDetRun + threadIdx.x;           // w[k] = group[j + k], |k| <= kDetRun
   const u64 g = w[0];
+  // the cell and this update's own target are requested NOW, before the run is scanned: the scattered
+  // read is the long pole of the kernel and the scan (tens of LDS reads) hides under it.  Every update
+  // asks, also the few that turn out to be folded by an earlier one or dropped (slot bits 0 then: a
+  // valid address); the compiler would not hoist the load above the early returns by itself
+  float* cell = det_cell(table, g);
+  const float cell0 = *cell;
+  const double target0 = target[j];
   // is an earlier update of the run in the same group (then that one folds this one in), and how
   // far does the run go
   bool first = true;
@@ -1312,10 +1323,9 @@ __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u
     return;
   }
   if (!first || (g & kDetDrop) != 0ull) return;                            // folded in by an earlier update / dropped
-  float* cell = det_cell(table, g);
-  double q = (double)*cell;
-  for (int k = 0; k <= fwd; ++k)
-    if (w[k] == g) q = td_fold(q, target[j + k], lr);                      // Agent/main.py:43, env order
+  double q = td_fold((double)cell0, target0, lr);                          // Agent/main.py:43, env order
+  for (int k = 1; k <= fwd; ++k)
+    if (w[k] == g) q = td_fold(q, target[j + k], lr);
   *cell = (float)q;
 }
 

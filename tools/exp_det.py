@@ -17,7 +17,7 @@ for B, steps in ((1 << 20, 96), (1 << 16, 256)):
     for mode in ("deterministic", "fused"):
         env = pkg.BatchedGame2048Env(B, seed=0, device=dev)
         agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99, exploration_rate=0.95,
-                                          capacity_log2=30, seed=0, device=dev, placement="plain")
+                                          capacity_log2=30, seed=0, device=dev)
         agent.fused_rollout(env, 256, play_only=True)      # mid-game boards
         agent.experiment_bits = int(os.environ.get("DET_BITS", "0"), 0) if mode == "deterministic" else 0
         go = agent.deterministic_rollout if mode == "deterministic" else agent.fused_rollout
