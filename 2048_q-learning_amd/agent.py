@@ -146,8 +146,8 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto"):
     API) measures as fast as one that spans 128 GiB, on every box so far.  `placement`:
       "auto"    tables of 1..32 GiB: "chunks"; smaller ones (cache-resident) and larger ones (fast
                 as they come) "plain"
-      "chunks"  q2048_table_alloc: 2 MiB physical chunks mapped into one virtual range (the faster of
-                two such tables when they fit in half of the free memory together)
+      "chunks"  q2048_table_alloc: 2 MiB physical chunks mapped into one virtual range (the fastest of
+                up to four such tables, as many as fit in half of the free memory together)
       "plain"   torch.zeros (caching allocator -> hipMalloc): whatever the device yields
       n (int)   allocate up to n plain candidates at once, time q2048_table_probe on each (~2 ms,
                 contents untouched), keep the fastest, release the others
@@ -165,10 +165,11 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto"):
     if placement == "plain":
         return torch.zeros(shape, dtype=torch.uint8, device=device), {"mode": "plain"}
     if placement == "chunks":
-        # two candidates when the device has the room: chunked tables differ less than hipMalloc'd ones,
-        # but one in five still probes ~7 % slower than the rest (54.8 against 50.6-51.6 us on 2^30 slots)
+        # up to four candidates when the device has the room: chunked tables differ less than hipMalloc'd
+        # ones, but on some boxes every second one still probes 10-15 % slower than the rest (57-59 against
+        # 49-51 us on 2^28 and 2^30 slots); each candidate costs its mapping + zero-fill (~0.3 s for 32 GiB)
         free, _ = torch.cuda.mem_get_info(device)
-        tries = 2 if 2 * nbytes <= 0.5 * free else 1
+        tries = int(max(1, min(4, (0.5 * free) // nbytes)))
         tables, times = [], []
         for _ in range(tries):
             tables.append(_ChunkedTable(capacity_log2, device).tensor(device))

@@ -1644,7 +1644,7 @@ def test_table_placements_give_the_same_learner(pkg):
             assert rep["probe_us"][rep["chosen"]] == min(rep["probe_us"]) > 0
         if placement == "chunks":
             assert rep["mode"] == "chunks" and min(rep["probe_us"]) > 0 and agent.table.data_ptr() % (2 << 20) == 0
-            assert rep["candidates"] == len(rep["probe_us"]) == 2 and rep["probe_us"][rep["chosen"]] == min(rep["probe_us"])
+            assert rep["candidates"] == len(rep["probe_us"]) == 4 and rep["probe_us"][rep["chosen"]] == min(rep["probe_us"])
         agent.fused_rollout(env, 24)           # eps = 1: trajectories do not depend on Q
         keys, q = agent.export_rows()
         order = np.argsort(keys)
