@@ -1047,12 +1047,12 @@ template <int N, int ENV>
 __global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
     uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, double* target_out,
-    uint32_t* carry, int use_carry, u64* longs, StatStripe* stat_stripes, uint32_t* status) {
+    uint32_t* carry, int use_carry, StatStripe* stat_stripes, uint32_t* gs0, int n_gs, uint32_t* status) {
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
   stats_clear(bs);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i == 0) longs[0] = 0ull;        // this step's list of long groups starts empty
+  for (int64_t idx = i; idx < (int64_t)n_gs; idx += (int64_t)gridDim.x * kBlock) gs0[idx] = 0u;   // the first pass's group sums
   auto b = load_board(boards, i, B, st);
   if (i < B) {
     const uint64_t id = env_id0 + (uint64_t)i;
@@ -1169,10 +1169,19 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, volatile uint32_
   return off + incl - v;
 }
 
+// Group sums (batches of up to 8 Mi updates): besides cnt[digit][tile] the tiles of a group of `gsz`
+// add their counts into gs[digit][group] -- 16-32 atomics per address -- and the scatter kernel adds up
+// the groups before its own and the tiles before it inside its group itself (<= 2 sqrt(T) cached
+// loads per digit): the separate scan launch (k_sort_scan, ~5 us of which most is the launch) is
+// gone.  `gs_next` is the other pass's buffer, zeroed here for the count kernel that follows.
 __global__ __launch_bounds__(kBlock) void k_sort_count(const u64* keys, int64_t B, int shift,
-                                                       uint32_t dmask, uint32_t* cnt, int64_t T) {
+                                                       uint32_t dmask, uint32_t* cnt, int64_t T,
+                                                       uint32_t* gs, uint32_t* gs_next, int n_groups, int gsz) {
   __shared__ uint32_t h[kBlock];
   h[threadIdx.x] = 0u;
+  if (gs_next != nullptr)
+    for (int idx = (int)(blockIdx.x * kBlock + threadIdx.x); idx < n_groups * kBlock; idx += (int)(gridDim.x * kBlock))
+      gs_next[idx] = 0u;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kSortTile;
 #pragma unroll
@@ -1181,7 +1190,13 @@ __global__ __launch_bounds__(kBlock) void k_sort_count(const u64* keys, int64_t 
     if (idx < B) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & dmask], 1u);
   }
   __syncthreads();
-  cnt[(int64_t)threadIdx.x * T + blockIdx.x] = h[threadIdx.x];
+  if (gs == nullptr) {                       // k_sort_scan's layout: one row of T tile counts per digit
+    cnt[(int64_t)threadIdx.x * T + blockIdx.x] = h[threadIdx.x];
+  } else {                                   // [tile][digit] and [group][digit]: every access of this kernel
+    cnt[(int64_t)blockIdx.x * kBlock + threadIdx.x] = h[threadIdx.x];       // and of the scatter is coalesced
+    if (h[threadIdx.x] != 0u)
+      atomicAdd(&gs[(int)(blockIdx.x / (unsigned)gsz) * kBlock + (int)threadIdx.x], h[threadIdx.x]);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_sort_scan(uint32_t* cnt, int64_t T, uint32_t* total) {
@@ -1204,7 +1219,8 @@ __global__ __launch_bounds__(kBlock) void k_sort_scan(uint32_t* cnt, int64_t T, 
 __global__ __launch_bounds__(kBlock) void k_sort_scatter(const u64* kin, const u64* vin, u64* kout,
                                                          u64* vout, int64_t B, int shift, uint32_t dmask,
                                                          const uint32_t* tile_before,
-                                                         const uint32_t* total, int64_t T) {
+                                                         const uint32_t* total, int64_t T,
+                                                         const uint32_t* gs, int n_groups, int gsz) {
   __shared__ u64 sk[kSortTile];
   __shared__ u64 sv[kSortTile];
   __shared__ uint32_t wcount[kSortWaves][kBlock];   // per wave and digit: pairs seen so far -> pairs of earlier waves
@@ -1226,6 +1242,23 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const u64* kin, const u
     k[r] = idx < B ? kin[idx] : 0ull;
     v[r] = idx < B ? vin[idx] : 0ull;
   }
+  // thread = digit: pairs of this digit in earlier tiles, and in all tiles (requested here, used after
+  // the ranking rounds).  tile_before is k_sort_scan's output (gs == nullptr) or the raw counts
+  uint32_t digit_before, digit_total;
+  if (gs != nullptr) {
+    const int grp = (int)(blockIdx.x / (unsigned)gsz);
+    uint32_t acc = 0u, tot = 0u;
+#pragma unroll 8                                         // independent loads: eight in flight, not one at a time
+    for (int g = 0; g < n_groups; ++g) { const uint32_t x = gs[g * kBlock + (int)tid]; tot += x; acc += g < grp ? x : 0u; }
+    const uint32_t* c = tile_before + ((int64_t)grp * gsz) * kBlock + tid;
+    const int n_before = (int)((int64_t)blockIdx.x - (int64_t)grp * gsz);
+#pragma unroll 8
+    for (int t = 0; t < n_before; ++t) acc += c[(int64_t)t * kBlock];
+    digit_before = acc; digit_total = tot;
+  } else {
+    digit_before = tile_before[(int64_t)tid * T + blockIdx.x];
+    digit_total = total[tid];
+  }
 #pragma unroll
   for (int r = 0; r < kSortRounds; ++r) {
     const bool act = base + r * 64 + lane < B;
@@ -1241,9 +1274,9 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const u64* kin, const u
     const uint32_t c0 = wc[0][tid], c1 = wc[1][tid], c2 = wc[2][tid], c3 = wc[3][tid];
     wc[0][tid] = 0u; wc[1][tid] = c0; wc[2][tid] = c0 + c1; wc[3][tid] = c0 + c1 + c2;
     const uint32_t in_tile = block_excl_scan(c0 + c1 + c2 + c3, ws);
-    const uint32_t smaller = block_excl_scan(total[tid], ws);
+    const uint32_t smaller = block_excl_scan(digit_total, ws);
     first[tid] = in_tile;
-    dest[tid] = smaller + tile_before[(int64_t)tid * T + blockIdx.x] - in_tile;
+    dest[tid] = smaller + digit_before - in_tile;
   }
   __syncthreads();
 #pragma unroll
@@ -1270,24 +1303,84 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const u64* kin, const u
 // of ~16, and inside a run the handful of distinct groups are told apart by comparing the full
 // words.  Agent/main.py:43 applied update by update in env order, in double precision, rounded to
 // float32 once per group and step -- td_fold(), the same operations in the same order on both paths
-// below (for a group of one that is exactly td_value()).
-//   k_det_apply       runs of up to kDetRun updates: the first update of every group in the run
-//                     folds the group's updates in env order and writes the cell (one lane per
-//                     update scans its run; ~700 000 independent read-modify-writes in flight).
-//                     Longer runs -- the states many envs share, e.g. right after a reset -- are
-//                     listed by their first update;
-//   k_det_apply_long  one wave per listed run, one LANE per group: the wave walks the run 64
-//                     updates at a time, broadcasts each update in order, and the lane that owns its
-//                     group folds it in (up to 64 groups per sweep of the run; more take further
-//                     sweeps).
+// below (for a group of one that is exactly td_value()).  One kernel, k_det_apply:
+//   runs of up to kDetRun updates: the first update of every group in the run folds the group's
+//     updates in env order and writes the cell (one lane per update scans its run; ~700 000
+//     independent read-modify-writes in flight);
+//   longer runs -- the states many envs share, e.g. right after a reset -- are folded by the WAVE of
+//     their first update once its lanes are done with their own short runs (fold_long_run: one LANE
+//     per group, the wave walks the run 64 updates at a time, broadcasts each update in order, and
+//     the lane that owns its group folds it in; up to 64 groups per sweep of the run, more take
+//     further sweeps).  Round 2 listed the long runs and folded them in a second launch; a launch
+//     costs ~5 us here whether or not there is a long run, and mid-game there is none.
 // kDetDone marks an update as applied (the sorted array is scratch).
 constexpr int kDetRun = 64;
 __device__ __forceinline__ float* det_cell(q2048_slot* table, u64 g) {
   return &table[(g & kDetSlotMask) >> 2].q[g & 3ull];
 }
-__global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u64* group,
+__device__ __forceinline__ u64 readlane64(u64 v, int lane) {
+  return (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane) |
+         ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32);
+}
+// the whole wave (all 64 lanes active) folds the run that starts at `start` (wave-uniform)
+__device__ __forceinline__ void fold_long_run(q2048_slot* table, u64* group, const double* target, int64_t B,
+                                              double lr, u64 run_mask, int64_t start, int lane) {
+  const u64 g0 = group[start];
+  int64_t len = 0;                                     // wave-uniform search for the run's end
+  for (;;) {
+    const int64_t pos = start + len + (int64_t)lane;
+    const u64 same = __ballot(pos < B && ((group[pos] ^ g0) & run_mask) == 0ull);
+    if (same != ~0ull) { len += (int64_t)(__ffsll((long long)~same) - 1); break; }
+    len += 64;
+  }
+  for (;;) {                                           // one sweep: the first <= 64 open groups
+    // (a) which groups: in order of first appearance, lane k owns the k-th
+    u64 mine = 0ull;                                   // 0 = none (owned words carry the kDetDone tag)
+    int n_owned = 0;
+    bool more = false;                                 // open groups beyond the 64 of this sweep
+    for (int64_t c = 0; c < len && !more; c += 64) {
+      const bool valid = c + lane < len;
+      const u64 g = valid ? group[start + c + lane] : kDetDone;
+      u64 open = __ballot((g & (kDetDone | kDetDrop)) == 0ull);
+      while (open != 0ull) {
+        const int k = __ffsll((long long)open) - 1;
+        open &= open - 1ull;
+        const u64 gk = readlane64(g, k) | kDetDone;    // tagged: never equals the "none" value 0
+        if (__ballot(mine == gk) != 0ull) continue;
+        if (n_owned == 64) { more = true; break; }
+        if (lane == n_owned) mine = gk;
+        ++n_owned;
+      }
+    }
+    if (n_owned == 0) break;
+    // (b) every owner reads its cell (one round trip for the whole sweep), then (c) the run is
+    // walked again: each open update is broadcast in order and folded by its group's lane
+    float* cell = det_cell(table, mine);
+    double q = lane < n_owned ? (double)*cell : 0.0;
+    for (int64_t c = 0; c < len; c += 64) {
+      const bool valid = c + lane < len;
+      const u64 g = valid ? group[start + c + lane] : kDetDone;
+      const double t = valid ? target[start + c + lane] : 0.0;
+      u64 open = __ballot((g & (kDetDone | kDetDrop)) == 0ull);
+      bool taken = false;
+      while (open != 0ull) {
+        const int k = __ffsll((long long)open) - 1;
+        open &= open - 1ull;
+        const u64 gk = readlane64(g, k) | kDetDone;
+        const double tk = __longlong_as_double((long long)readlane64((u64)__double_as_longlong(t), k));
+        const bool own = mine == gk;
+        if (own) q = td_fold(q, tk, lr);               // Agent/main.py:43, env order
+        if (__ballot(own) != 0ull && lane == k) taken = true;
+      }
+      if (taken) group[start + c + lane] = g | kDetDone;
+    }
+    if (lane < n_owned) *cell = (float)q;
+    if (!more) break;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, u64* group,
                                                       const double* target, int64_t B, double lr,
-                                                      u64 run_mask, u64* longs) {
+                                                      u64 run_mask) {
   // the block's 256 sorted words and kDetRun neighbours on either side, staged once: every
   // update scans its run (tens of words) and that traffic belongs in LDS, not in the L1
   __shared__ u64 tile[kBlock + 2 * kDetRun];
@@ -1298,101 +1391,40 @@ __global__ __launch_bounds__(kBlock) void k_det_apply(q2048_slot* table, const u
   }
   __syncthreads();
   const int64_t j = base + threadIdx.x;
-  if (j >= B) return;
-  const u64* w = tile + kDetRun + threadIdx.x;           // w[k] = group[j + k], |k| <= kDetRun
+  const bool live = j < B;                               // (no early return: the wave stays whole for the long runs)
+  const int64_t jj = live ? j : B - 1;
+  const u64* w = tile + kDetRun + (live ? (int)threadIdx.x : (int)(B - 1 - base));   // w[k] = group[jj + k], |k| <= kDetRun
   const u64 g = w[0];
   // the cell and this update's own target are requested NOW, before the run is scanned: the scattered
   // read is the long pole of the kernel and the scan (tens of LDS reads) hides under it.  Every update
   // asks, also the few that turn out to be folded by an earlier one or dropped (slot bits 0 then: a
-  // valid address); the compiler would not hoist the load above the early returns by itself
+  // valid address)
   float* cell = det_cell(table, g);
   const float cell0 = *cell;
-  const double target0 = target[j];
+  const double target0 = target[jj];
   // is an earlier update of the run in the same group (then that one folds this one in), and how
   // far does the run go
   bool first = true;
   int back = 0, fwd = 0;
-  while (back < kDetRun && j - back - 1 >= 0 && ((w[-back - 1] ^ g) & run_mask) == 0ull) {
+  while (back < kDetRun && jj - back - 1 >= 0 && ((w[-back - 1] ^ g) & run_mask) == 0ull) {
     first = first && w[-back - 1] != g;
     ++back;
   }
-  while (fwd < kDetRun && j + fwd + 1 < B && ((w[fwd + 1] ^ g) & run_mask) == 0ull) ++fwd;
-  if (back + fwd + 1 > kDetRun) {    // a long run (every update of it sees that): the wave kernel's
-    if (back == 0)                   // its head lists it; at most B / 65 such runs, no overflow
-      longs[1ull + atomicAdd(&longs[0], 1ull)] = (u64)j;
-    return;
+  while (fwd < kDetRun && jj + fwd + 1 < B && ((w[fwd + 1] ^ g) & run_mask) == 0ull) ++fwd;
+  const bool long_run = back + fwd + 1 > kDetRun;        // every update of a long run sees that
+  if (live && !long_run && first && (g & kDetDrop) == 0ull) {
+    double q = td_fold((double)cell0, target0, lr);                        // Agent/main.py:43, env order
+    for (int k = 1; k <= fwd; ++k)
+      if (w[k] == g) q = td_fold(q, target[j + k], lr);
+    *cell = (float)q;
   }
-  if (!first || (g & kDetDrop) != 0ull) return;                            // folded in by an earlier update / dropped
-  double q = td_fold((double)cell0, target0, lr);                          // Agent/main.py:43, env order
-  for (int k = 1; k <= fwd; ++k)
-    if (w[k] == g) q = td_fold(q, target[j + k], lr);
-  *cell = (float)q;
-}
-
-__device__ __forceinline__ u64 readlane64(u64 v, int lane) {
-  return (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane) |
-         ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32);
-}
-__global__ __launch_bounds__(kBlock) void k_det_apply_long(q2048_slot* table, u64* group,
-                                                           const double* target, int64_t B, double lr,
-                                                           u64 run_mask, const u64* longs) {
-  const u64 n_long = longs[0];
+  // long runs whose first update sits in this wave: the wave folds them, one after the other
   const int lane = (int)(threadIdx.x & 63u);
-  const u64 waves = (u64)gridDim.x * (kBlock / 64);
-  for (u64 w = (u64)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n_long; w += waves) {
-    const int64_t start = (int64_t)longs[1ull + w];
-    const u64 g0 = group[start];
-    int64_t len = 0;                                     // wave-uniform search for the run's end
-    for (;;) {
-      const int64_t pos = start + len + (int64_t)lane;
-      const u64 same = __ballot(pos < B && ((group[pos] ^ g0) & run_mask) == 0ull);
-      if (same != ~0ull) { len += (int64_t)(__ffsll((long long)~same) - 1); break; }
-      len += 64;
-    }
-    for (;;) {                                           // one sweep: the first <= 64 open groups
-      // (a) which groups: in order of first appearance, lane k owns the k-th
-      u64 mine = 0ull;                                   // 0 is no group word (h16 | slot | action of a live update is never all zero: see below)
-      int n_owned = 0;
-      bool more = false;                                 // open groups beyond the 64 of this sweep
-      for (int64_t c = 0; c < len && !more; c += 64) {
-        const bool valid = c + lane < len;
-        const u64 g = valid ? group[start + c + lane] : kDetDone;
-        u64 open = __ballot((g & (kDetDone | kDetDrop)) == 0ull);
-        while (open != 0ull) {
-          const int k = __ffsll((long long)open) - 1;
-          open &= open - 1ull;
-          const u64 gk = readlane64(g, k) | kDetDone;    // tagged: never equals the "none" value 0
-          if (__ballot(mine == gk) != 0ull) continue;
-          if (n_owned == 64) { more = true; break; }
-          if (lane == n_owned) mine = gk;
-          ++n_owned;
-        }
-      }
-      if (n_owned == 0) break;
-      // (b) every owner reads its cell (one round trip for the whole sweep), then (c) the run is
-      // walked again: each open update is broadcast in order and folded by its group's lane
-      float* cell = det_cell(table, mine);
-      double q = lane < n_owned ? (double)*cell : 0.0;
-      for (int64_t c = 0; c < len; c += 64) {
-        const bool valid = c + lane < len;
-        const u64 g = valid ? group[start + c + lane] : kDetDone;
-        const double t = valid ? target[start + c + lane] : 0.0;
-        u64 open = __ballot((g & (kDetDone | kDetDrop)) == 0ull);
-        bool taken = false;
-        while (open != 0ull) {
-          const int k = __ffsll((long long)open) - 1;
-          open &= open - 1ull;
-          const u64 gk = readlane64(g, k) | kDetDone;
-          const double tk = __longlong_as_double((long long)readlane64((u64)__double_as_longlong(t), k));
-          const bool own = mine == gk;
-          if (own) q = td_fold(q, tk, lr);               // Agent/main.py:43, env order
-          if (__ballot(own) != 0ull && lane == k) taken = true;
-        }
-        if (taken) group[start + c + lane] = g | kDetDone;
-      }
-      if (lane < n_owned) *cell = (float)q;
-      if (!more) break;
-    }
+  u64 heads = __ballot(live && long_run && back == 0);
+  while (heads != 0ull) {
+    const int k = __ffsll((long long)heads) - 1;
+    heads &= heads - 1ull;
+    fold_long_run(table, group, target, B, lr, run_mask, (int64_t)readlane64((u64)j, k), lane);
   }
 }
 
@@ -2005,18 +2037,23 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
 // workspace of q2048_det_rollout: double-buffered (group, target) pairs, the slot every env holds
 // for its next step, the list of long groups, the sort's per-tile digit counts and digit totals;
 // every part 256-byte aligned
-struct DetLayout { size_t group[2], target[2], carry, longs, cnt, total_cnt, stripes, total; int64_t tiles; };
+struct DetLayout { size_t group[2], target[2], carry, cnt, total_cnt, stripes, gs[2], total; int64_t tiles; int gsz, n_groups; };
 static int det_layout(int64_t B, int, DetLayout& L) {
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t at = 0;
   for (int k = 0; k < 2; ++k) { L.group[k] = at; at += up((size_t)B * 8); }
   for (int k = 0; k < 2; ++k) { L.target[k] = at; at += up((size_t)B * 8); }
   L.carry = at; at += up((size_t)B * 4);
-  L.longs = at; at += up(((size_t)B / (kDetRun + 1) + 2) * 8);
   L.tiles = (B + kSortTile - 1) / kSortTile;
   L.cnt = at; at += up((size_t)L.tiles * kBlock * 4);
   L.total_cnt = at; at += up((size_t)kBlock * 4);
   L.stripes = at; at += up(sizeof(StatStripe) * kStatStripes);
+  // group sums of the partition (see k_sort_count): groups of gsz = 2^ceil(log2(sqrt(T))) tiles; batches
+  // beyond 8 Mi updates (T > 4096) keep the separate scan launch
+  L.gsz = 1;
+  while ((int64_t)L.gsz * L.gsz < L.tiles) L.gsz <<= 1;
+  L.n_groups = L.tiles <= 4096 ? (int)((L.tiles + L.gsz - 1) / L.gsz) : 0;
+  for (int k = 0; k < 2; ++k) { L.gs[k] = at; at += up((size_t)L.n_groups * kBlock * 4); }
   L.total = at;
   return Q2048_OK;
 }
@@ -2053,7 +2090,7 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   uint32_t* carry = reinterpret_cast<uint32_t*>(ws + L.carry);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + L.cnt);
   uint32_t* total_cnt = reinterpret_cast<uint32_t*>(ws + L.total_cnt);
-  u64* longs = reinterpret_cast<u64*>(ws + L.longs);
+  uint32_t* gs[2] = {reinterpret_cast<uint32_t*>(ws + L.gs[0]), reinterpret_cast<uint32_t*>(ws + L.gs[1])};
   const hipStream_t s = (hipStream_t)stream;
   // statistics: striped copies in the workspace, folded into the caller's vectors once per call
   StatStripe* stripes = (stats_i != nullptr || stats_f != nullptr) ? reinterpret_cast<StatStripe*>(ws + L.stripes) : nullptr;
@@ -2070,22 +2107,23 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   const u64 run_mask = ((1ull << sort_hi) - 1ull) & ~((1ull << sort_lo) - 1ull);
   for (int64_t t = 0; t < steps; ++t) {
     Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
-                     ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), longs,
-                     stripes, status);
+                     ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), stripes, gs[0],
+                     L.n_groups * kBlock, status);
     int cur = 0;                                     // which buffer holds the pairs
-    for (int lo = sort_lo; lo < sort_hi; lo += 8, cur ^= 1) {
+    for (int lo = sort_lo, pass = 0; lo < sort_hi; lo += 8, cur ^= 1, ++pass) {
       const uint32_t dmask = sort_hi - lo >= 8 ? 255u : (1u << (sort_hi - lo)) - 1u;
+      uint32_t* gs_now = L.n_groups ? gs[pass & 1] : nullptr;
       hipLaunchKernelGGL(k_sort_count, dim3((unsigned)L.tiles), dim3(kBlock), 0, s, group[cur], B, lo, dmask,
-                         cnt, L.tiles);
-      hipLaunchKernelGGL(k_sort_scan, dim3(kBlock), dim3(kBlock), 0, s, cnt, L.tiles, total_cnt);
+                         cnt, L.tiles, gs_now, L.n_groups ? gs[(pass + 1) & 1] : nullptr, L.n_groups, L.gsz);
+      if (gs_now == nullptr)
+        hipLaunchKernelGGL(k_sort_scan, dim3(kBlock), dim3(kBlock), 0, s, cnt, L.tiles, total_cnt);
       hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)L.tiles), dim3(kBlock), 0, s, group[cur],
                          reinterpret_cast<const u64*>(target[cur]), group[cur ^ 1],
-                         reinterpret_cast<u64*>(target[cur ^ 1]), B, lo, dmask, cnt, total_cnt, L.tiles);
+                         reinterpret_cast<u64*>(target[cur ^ 1]), B, lo, dmask, cnt, total_cnt, L.tiles,
+                         gs_now, L.n_groups, L.gsz);
     }
     hipLaunchKernelGGL(k_det_apply, dim3(grid_for(B)), dim3(kBlock), 0, s, table, group[cur], target[cur], B, lr,
-                       run_mask, longs);
-    hipLaunchKernelGGL(k_det_apply_long, dim3(256), dim3(kBlock), 0, s, table, group[cur], target[cur], B, lr,
-                       run_mask, longs);
+                       run_mask);
     if (int e = launch_status()) return e;
   }
   if (stripes != nullptr)

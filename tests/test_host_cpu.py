@@ -47,7 +47,7 @@ def test_abi_exports_every_declared_symbol(pkg):
     X = pkg._native.load(pkg._native.build_experiments())        # same ABI, same symbols
     for name in sorted(declared):
         assert hasattr(X, name)
-    # the deterministic mode's workspace is host arithmetic: pairs twice over, slots, long-run list, counts
+    # the deterministic mode's workspace is host arithmetic: pairs twice over, slots, counts, statistics stripes
     small, big = L.q2048_det_workspace_bytes(1, 20), L.q2048_det_workspace_bytes(1 << 20, 32)
     assert 0 < small < 1 << 20 and small % 256 == 0
     assert 36 * (1 << 20) <= big <= 40 * (1 << 20) and big % 256 == 0
