@@ -373,8 +373,8 @@ class BatchedQLearningAgent:
         table as it is at the start of the step, the updates are sorted on the device by a hash of
         (state, action) and each group is applied update by update in env order.  The result is a
         function of the inputs alone and equals the reference agent (with float32 rows) fed the same
-        transitions in env order -- bit for bit, at any B (tested at 1 048 576 boards).  Eight launches
-        per step, 6.7-6.9e9 env-steps/s at 1 Mi boards: `fused_rollout` is the fast path, this one is
+        transitions in env order -- bit for bit, at any B (tested at 1 048 576 boards).  Six launches
+        per step, 7.2e9 env-steps/s at 1 Mi boards: `fused_rollout` is the fast path, this one is
         the yard-stick."""
         if env.device != self.device or env.board_size != self.board_size:
             raise ValueError("env and agent do not match")
