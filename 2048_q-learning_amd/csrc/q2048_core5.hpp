@@ -35,73 +35,102 @@ Q_HD void clear(Board5& b) {
   for (int i = 0; i < 5; ++i) b.r[i] = 0u;
 }
 
-// out word j = column j (field i = row i)
+// (a & m) | (b & ~m) for a mask m that is a compile-time constant: on the device as ONE v_bfi_b32
+// (the compiler otherwise folds a constant mask into shift / and / or: three instructions a cell)
+Q_HD uint32_t bsel_const(uint32_t m, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t d;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(m), "v"(a), "v"(b));
+  return d;
+#else
+  return bsel(m, a, b);
+#endif
+}
+
+// the same for a per-lane mask of all ones or all zeros: the word-wise selects of move().  (Written
+// as `cond ? p[4 - j] : p[j]` the compiler turns them into a dynamically indexed array, four
+// v_cndmask a word.)
+Q_HD uint32_t bsel_lane(uint32_t m, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t d;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+  return d;
+#else
+  return bsel(m, a, b);
+#endif
+}
+
+// out word j = column j (field i = row i): one shift and one bit-select per off-diagonal cell
 Q_HD Board5 transpose(const Board5& b) {
   Board5 t;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
-    uint32_t w = 0;
+    uint32_t w = b.r[j] & (63u << (6 * j));
 #pragma unroll
-    for (int i = 0; i < 5; ++i) w |= field5(b.r[i], j) << (6 * i);
+    for (int i = 0; i < 5; ++i)
+      if (i != j) w = bsel_const(63u << (6 * i), i < j ? b.r[i] >> (6 * (j - i)) : b.r[i] << (6 * (i - j)), w);
     t.r[j] = w;
   }
   return t;
 }
 
-Q_HD uint32_t pow2_sum5(uint32_t v) {  // sum over the five fields f of (f ? 2^f : 0), f >= 2
+// sum over the five fields f of 2^f (an empty field counts 1: the caller takes those off again)
+Q_HD uint32_t pow2_sum5_raw(uint32_t v) {
   uint32_t s = 0;
 #pragma unroll
-  for (int c = 0; c < 5; ++c) s += (1u << field5(v, c)) & ~1u;
+  for (int c = 0; c < 5; ++c) s += 1u << field5(v, c);
   return s;
 }
 
 // move_left (Game2048_env.py:25-44) on five lines at once; c[j] = cell j of every line
 Q_HD uint32_t slide_lines(uint32_t (&c)[5]) {
-  // compress (:26)
+  // compress (:26): empty cells bubble to the far end, tiles keep their order (ten neighbour swaps)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int pass = 0; pass < 4; ++pass) {
 #pragma unroll
-    for (int rep = 0; rep < 4 - t; ++rep) {
-      const uint32_t z = fill5(z5(c[t]));
-#pragma unroll
-      for (int k = t; k < 4; ++k) c[k] = bsel(z, c[k + 1], c[k]);
-      c[4] &= ~z;
+    for (int k = 0; k < 4 - pass; ++k) {
+      const uint32_t z = fill5(z5(c[k]));
+      c[k] |= c[k + 1] & z;
+      c[k + 1] &= ~z;
     }
   }
-  // merge (:29-40): pairs left to right, a merged tile never merges again
-  uint32_t score = 0;
+  // merge (:29-40): pairs left to right, a merged tile never merges again.  A line merges at most
+  // twice, and a merge at t = 3 (cells 3 and 4 equal and not empty: nothing moved up before) is its
+  // only one, so the merged tiles of t = 0 and t = 3 share one word.
+  uint32_t merged[4], n = 0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const uint32_t e = z5(c[t] ^ c[t + 1]) & nz5(c[t]);
+    const uint32_t e = ~((c[t] ^ c[t + 1]) + k5Low) & (c[t] + k5Low) & k5High;
     const uint32_t m = fill5(e);
     c[t] += e >> 5;
-    score += pow2_sum5(c[t] & m);  // :36
+    merged[t] = c[t] & m;  // :36
+    n += popc(e);
 #pragma unroll
     for (int k = t + 1; k < 4; ++k) c[k] = bsel(m, c[k + 1], c[k]);
     c[4] &= ~m;
   }
-  return score;
+  return pow2_sum5_raw(merged[0] | merged[3]) + pow2_sum5_raw(merged[1]) + pow2_sum5_raw(merged[2]) - (15u - n);
 }
 
 // Game2048.move without the spawn (:51-60); 0 left, 1 up, 2 right, 3 down (:54)
 Q_HD bool move(Board5& b, int action, uint32_t& score) {
-  const bool horiz = (action & 1) == 0, rev = (action & 2) != 0;
+  const uint32_t horiz = (action & 1) == 0 ? ~0u : 0u, rev = (action & 2) != 0 ? ~0u : 0u;
   const Board5 t = transpose(b);
   uint32_t p[5], c[5], o[5];
 #pragma unroll
-  for (int j = 0; j < 5; ++j) p[j] = horiz ? t.r[j] : b.r[j];
+  for (int j = 0; j < 5; ++j) p[j] = bsel_lane(horiz, t.r[j], b.r[j]);
 #pragma unroll
-  for (int j = 0; j < 5; ++j) { c[j] = rev ? p[4 - j] : p[j]; o[j] = c[j]; }
+  for (int j = 0; j < 5; ++j) { c[j] = j == 2 ? p[2] : bsel_lane(rev, p[4 - j], p[j]); o[j] = c[j]; }
   score = slide_lines(c);
   uint32_t diff = 0;
 #pragma unroll
   for (int j = 0; j < 5; ++j) diff |= c[j] ^ o[j];
   Board5 q;
 #pragma unroll
-  for (int j = 0; j < 5; ++j) q.r[j] = rev ? c[4 - j] : c[j];
+  for (int j = 0; j < 5; ++j) q.r[j] = j == 2 ? c[2] : bsel_lane(rev, c[4 - j], c[j]);
   const Board5 qt = transpose(q);
 #pragma unroll
-  for (int j = 0; j < 5; ++j) b.r[j] = horiz ? qt.r[j] : q.r[j];
+  for (int j = 0; j < 5; ++j) b.r[j] = bsel_lane(horiz, qt.r[j], q.r[j]);
   return diff != 0;  // :38,42-43
 }
 

@@ -69,6 +69,7 @@ template <> struct Geo<5> {
 // and the single-step 5x5 kernel ran at 0.40 of the roofline).  Empty for 4x4.
 template <int N, int WAVES = kBlock / 64> struct Stage { };
 template <int WAVES> struct Stage<5, WAVES> { uint4 v[WAVES][100]; };
+typedef __attribute__((address_space(3))) uint8_t lds_u8;   // a byte in LDS (volatile accesses through a generic pointer would be flat_*)
 __device__ __forceinline__ void wave_lds_sync() {      // this wave's LDS writes are done before its next LDS reads
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -100,11 +101,26 @@ __device__ __forceinline__ Board5 load_board(const uint8_t* boards, int64_t i, i
   uint4* lds = st.v[w];
   uint8_t* l8 = reinterpret_cast<uint8_t*>(lds);
   for (int c = lane; c * 16 < bytes; c += 64) {
-    if (c * 16 + 16 <= bytes) lds[c] = reinterpret_cast<const uint4*>(src)[c];
-    else for (int k = c * 16; k < bytes; ++k) l8[k] = src[k];  // ragged tail of the batch's last wave
+    if (c * 16 + 16 <= bytes) {
+      uint4 v = reinterpret_cast<const uint4*>(src)[c];
+      v.x &= 0x1f1f1f1fu; v.y &= 0x1f1f1f1fu; v.z &= 0x1f1f1f1fu; v.w &= 0x1f1f1f1fu;   // log2 tile <= 31
+      lds[c] = v;
+    } else for (int k = c * 16; k < bytes; ++k) l8[k] = src[k] & 31u;  // ragged tail of the batch's last wave
   }
   wave_lds_sync();
-  if (i < B) b = board5_from_bytes(l8 + lane * 25);
+  // One LDS byte read and one v_lshl_or per cell (the LDS pipe is idle otherwise; taking the 25
+  // bytes as seven words and pulling the fields out of them costs the VALU, which bounds the 5x5
+  // env step, twice the instructions).  volatile: the compiler would merge the reads into words.
+  if (i < B) {
+    const volatile lds_u8* mine = (const volatile lds_u8*)(l8 + lane * 25);
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      uint32_t w = mine[5 * r];
+#pragma unroll
+      for (int c = 1; c < 5; ++c) w |= (uint32_t)mine[5 * r + c] << (6 * c);
+      b.r[r] = w;
+    }
+  }
   wave_lds_sync();                                      // the slice is written again by store_board
   return b;
 }
@@ -119,7 +135,13 @@ __device__ __forceinline__ void store_board(uint8_t* boards, int64_t i, int64_t 
   uint8_t* dst = boards + base * 25;
   uint4* lds = st.v[w];
   uint8_t* l8 = reinterpret_cast<uint8_t*>(lds);
-  if (i < B) board5_to_bytes(b, l8 + lane * 25);
+  if (i < B) {                                          // one v_bfe and one LDS byte write per cell
+    volatile lds_u8* mine = (volatile lds_u8*)(l8 + lane * 25);
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) mine[5 * r + c] = (uint8_t)(field5(b.r[r], c) & 31u);
+  }
   wave_lds_sync();
   for (int c = lane; c * 16 < bytes; c += 64) {
     if (c * 16 + 16 <= bytes) reinterpret_cast<uint4*>(dst)[c] = lds[c];
@@ -2105,6 +2127,7 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
     else if (xb == 63) sort_lo = 0;
   }
   const u64 run_mask = ((1ull << sort_hi) - 1ull) & ~((1ull << sort_lo) - 1ull);
+  if (Q2048_XBITS(flags, 14, 1u)) L.n_groups = 0;   // experiment builds: the partition with its scan launch (the path of batches > 8 Mi)
   for (int64_t t = 0; t < steps; ++t) {
     Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
                      ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), stripes, gs[0],

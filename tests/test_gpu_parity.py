@@ -1469,7 +1469,8 @@ def test_c_host_program_drives_the_abi(pkg, tmp_path):
 
 @pytest.mark.parametrize("n,B,steps,sort_bits", [(4, 3000, 80, 0), (5, 1500, 60, 0), (4, 60000, 24, 0),
                                                   (4, 3000, 80, 3), (5, 1500, 60, 8), (4, 60000, 24, 63),
-                                                  (4, 60000, 24, 10), (4, 2500, 330, 0), (5, 2100, 300, 0)])
+                                                  (4, 60000, 24, 10), (4, 2500, 330, 0), (5, 2100, 300, 0),
+                                                  (4, 60000, 24, 64), (4, 5000, 40, 64 + 8)])
 def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, monkeypatch, n, B, steps, sort_bits):
     """Shared table, lanes meeting on common states, epsilon < 1 (actions depend on Q): the
     deterministic mode equals the oracle's two-phase semantic with float32 rows (the oracle's
@@ -1480,7 +1481,8 @@ def test_deterministic_mode_matches_oracle_on_a_shared_table(pkg, O, monkeypatch
     same sources with -DQ2048_EXPERIMENTS): the updates are then sorted by the low 3 / 8 / 10 bits
     of the 16-bit (state, action) hash, which makes every run of the sorted array a crowd of
     different groups (each told apart by the full word) or mixes long runs with crowded ones, or by
-    the whole word (63: a run is a group)."""
+    the whole word (63: a run is a group); + 64 selects the partition with its separate scan launch,
+    the path batches beyond 8 Mi updates take (the default builds the prefix from group sums)."""
     seed, id0, eps, lr, gamma = 41, 10, 0.2, 0.1, 0.95
     cells = n * n
     if sort_bits:
