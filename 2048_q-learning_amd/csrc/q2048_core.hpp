@@ -300,6 +300,14 @@ struct StepOut {
   uint8_t done, max_log2, valid;
 };
 
+// the spawn of a valid move (Game2048_env.py:61-62), then is_game_over (:99); the 5x5 board has its
+// own version that counts the empty cells once for both
+template <class BoardT>
+Q_HD bool spawn_then_over(BoardT& b, bool valid, uint32_t x_pos, uint32_t x_val) {
+  if (valid) spawn(b, x_pos, x_val);
+  return game_over(b);
+}
+
 // Game2048_env.step (:97-129) for one lane.  x_pos/x_val are the spawn draws.  BoardT is the
 // 4x4 Board above or the 5x5 Board5 of q2048_core5.hpp (same functions, overloaded).
 template <class BoardT>
@@ -307,8 +315,7 @@ Q_HD StepOut env_step(BoardT& b, Aux& a, int action, uint32_t x_pos, uint32_t x_
   StepOut o;
   uint32_t score;
   const bool valid = move(b, action, score);                            // :98
-  if (valid) spawn(b, x_pos, x_val);                                    // :61-62
-  const bool over = game_over(b);                                       // :99
+  const bool over = spawn_then_over(b, valid, x_pos, x_val);            // :61-62, :99
   const uint32_t mx = max_log2(b);                                      // :100
   a.score += (int32_t)score;                                            // :104
   double r = calculate_reward(score, valid, over, mx, a.prev_max);      // :107

@@ -156,19 +156,34 @@ Q_HD uint32_t kth_set_bit32(uint32_t mask, uint32_t k) {
   return pos;
 }
 
-Q_HD void put_cell(Board5& b, uint32_t pos, uint32_t v) {
-  const uint32_t row = (pos * 52429u) >> 18;  // pos / 5 for pos < 25
-  const uint32_t w = v << (6u * (pos - 5u * row));
+// Game2048.add_number (:16-20) without a dense cell mask: the k-th empty cell in row-major order is
+// the (k - empties of the rows above)-th empty field of its row, found on that row's guard bits
+// (clear the lowest set bit that many times, isolate the next).  Returns the number of empty
+// cells BEFORE the spawn; spawns only if `place` (and a cell is free, :18).
+Q_HD uint32_t spawn_counted(Board5& b, bool place, uint32_t draw_pos, uint32_t draw_val) {
+  uint32_t g[5], before[6];
+  before[0] = 0u;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { g[i] = z5(b.r[i]); before[i + 1] = before[i] + popc(g[i]); }
+  const uint32_t n = before[5];
+  if (!place || n == 0u) return n;
+  const uint32_t k = draw_index(draw_pos, n);
+  uint32_t x = g[0], base = 0u, row = 0u;
+#pragma unroll
+  for (int i = 1; i < 5; ++i) {
+    const bool ge = k >= before[i];
+    x = ge ? g[i] : x; base = ge ? before[i] : base; row += ge ? 1u : 0u;
+  }
+  const uint32_t skip = k - base;
+#pragma unroll
+  for (uint32_t j = 0; j < 4u; ++j) x = skip > j ? x & (x - 1u) : x;
+  x &= 0u - x;                                              // guard bit (6c + 5) of the chosen cell
+  const uint32_t w = x >> (draw_is_four(draw_val) ? 4u : 5u);  // log2 tile 2 or 1 in its field
 #pragma unroll
   for (int i = 0; i < 5; ++i) b.r[i] |= row == (uint32_t)i ? w : 0u;
+  return n;
 }
-
-// Game2048.add_number (:16-20)
-Q_HD void spawn(Board5& b, uint32_t draw_pos, uint32_t draw_val) {
-  const uint32_t em = empty_mask(b), n = popc(em);
-  if (n == 0u) return;  // :18
-  put_cell(b, kth_set_bit32(em, draw_index(draw_pos, n)), draw_is_four(draw_val) ? 2u : 1u);
-}
+Q_HD void spawn(Board5& b, uint32_t draw_pos, uint32_t draw_val) { spawn_counted(b, true, draw_pos, draw_val); }
 
 // Game2048.is_game_over (:65-75), closed form
 Q_HD bool game_over(const Board5& b) {
@@ -180,6 +195,26 @@ Q_HD bool game_over(const Board5& b) {
     if (i < 4) live |= z5(b.r[i] ^ b.r[i + 1]);                  // equal vertical neighbours
   }
   return live == 0u;
+}
+
+// On a board WITHOUT empty cells: does some cell equal a neighbour?  (A field of x + 0x1f keeps its
+// guard bit clear iff the field of x is 0.  Field 4 of r ^ (r >> 6) is cell 4 itself: never 0 here.)
+Q_HD bool equal_neighbours_on_full(const Board5& b) {
+  uint32_t acc = k5High;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    acc &= (b.r[i] ^ (b.r[i] >> 6)) + k5Low;
+    if (i < 4) acc &= (b.r[i] ^ b.r[i + 1]) + k5Low;
+  }
+  return (acc & k5High) != k5High;
+}
+
+// the spawn of a valid move (Game2048_env.py:61-62) and is_game_over (:99) after it, sharing the
+// count of empty cells
+Q_HD bool spawn_then_over(Board5& b, bool valid, uint32_t draw_pos, uint32_t draw_val) {
+  const uint32_t n = spawn_counted(b, valid, draw_pos, draw_val);
+  const uint32_t left = n - ((valid && n != 0u) ? 1u : 0u);
+  return left == 0u && !equal_neighbours_on_full(b);
 }
 
 Q_HD uint32_t fieldmax5(uint32_t a, uint32_t b) {
