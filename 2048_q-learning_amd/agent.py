@@ -144,8 +144,9 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto"):
     comes back in a slow or a fast state depending on where it lands, small ones nearly always slow,
     while the same table mapped from 2 MiB physical chunks (q2048_table_alloc: HIP virtual-memory
     API) measures as fast as one that spans 128 GiB, on every box so far.  `placement`:
-      "auto"    tables of 1..32 GiB: "chunks"; smaller ones (cache-resident) and larger ones (fast
-                as they come) "plain"
+      "auto"    tables of 1..64 GiB: "chunks"; smaller ones (cache-resident) and 128 GiB ones (fast as
+                they come: 42.4 us per step from hipMalloc, 42.7 from chunks, four processes each on one
+                box; a 64 GiB hipMalloc took 44.3 once and 49.4 three times, chunks 43.6-44.3) "plain"
       "chunks"  q2048_table_alloc: 2 MiB physical chunks mapped into one virtual range (the fastest of
                 up to four such tables, as many as fit in half of the free memory together)
       "plain"   torch.zeros (caching allocator -> hipMalloc): whatever the device yields
@@ -155,7 +156,7 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto"):
     shape = (1 << capacity_log2, N.SIZEOF_SLOT)
     nbytes = N.SIZEOF_SLOT << capacity_log2
     if placement == "auto":
-        if (1 << 30) <= nbytes <= (32 << 30):
+        if (1 << 30) <= nbytes <= (64 << 30):
             try:
                 return place_table(capacity_log2, device, "chunks")
             except (N.NativeError, RuntimeError) as exc:      # no virtual-memory API on this stack, or no room:
