@@ -258,8 +258,7 @@ class BatchedQLearningAgent:
         self.experiment_bits = 0  # unstable tuning bits OR-ed into fused_rollout's flags
         self.ctr = 0  # choose_action calls so far = counter word of the step draws
         self.table, self.placement = place_table(self.capacity_log2, self.device, placement)
-        self.stats_i = torch.zeros(N.NSTAT_I, dtype=torch.int64, device=self.device)
-        self.stats_f = torch.zeros(N.NSTAT_F, dtype=torch.float64, device=self.device)
+        self.stats_i, self.stats_f = new_stats_vectors(self.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.q_table = _QTableView(self)
         self.row_cache_enabled = bool(row_cache)
@@ -544,8 +543,7 @@ class BatchedRowTupleAgent:
         self.schedule = EpsilonSchedule(total_epochs, exploration_rate, exploration_min)
         self.seed, self.env_id0, self.ctr, self.board_size = int(seed), int(env_id0), 0, 4
         self.weights = torch.zeros((4, 65536, 4), dtype=torch.float32, device=self.device)
-        self.stats_i = torch.zeros(N.NSTAT_I, dtype=torch.int64, device=self.device)
-        self.stats_f = torch.zeros(N.NSTAT_F, dtype=torch.float64, device=self.device)
+        self.stats_i, self.stats_f = new_stats_vectors(self.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     epsilon = property(lambda self: self.schedule.epsilon,
@@ -619,6 +617,13 @@ class BatchedRowTupleAgent:
             self.status.zero_()
             raise ValueError("an action outside 0..3 was passed to update_q_value()")
         return s
+
+
+def new_stats_vectors(device):
+    """The two statistics vectors as views of ONE device buffer (int64 part, then float64 part), so
+    that a reader (`StatsAllReduce`) can take them with one copy."""
+    raw = torch.zeros((N.NSTAT_I + N.NSTAT_F) * 8, dtype=torch.uint8, device=device)
+    return raw[:N.NSTAT_I * 8].view(torch.int64), raw[N.NSTAT_I * 8:].view(torch.float64)
 
 
 def stats_dict(si, sf) -> dict:

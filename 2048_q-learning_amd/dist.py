@@ -86,12 +86,26 @@ def allreduce_stats(stats_i: torch.Tensor, stats_f: torch.Tensor, group=None):
     return stats_i, stats_f
 
 
+def _packed(stats_i: torch.Tensor, stats_f: torch.Tensor):
+    """The uint8 buffer both vectors are views of (agent.new_stats_vectors), or None."""
+    base = stats_i._base
+    if (base is None or base is not stats_f._base or base.dtype != torch.uint8 or base.dim() != 1
+            or base.numel() != (N.NSTAT_I + N.NSTAT_F) * 8 or not base.is_contiguous()
+            or stats_i.data_ptr() != base.data_ptr() or stats_f.data_ptr() != base.data_ptr() + N.NSTAT_I * 8):
+        return None
+    return base
+
+
 class StatsAllReduce:
     """The statistics all-reduce on a stream of its own: `start` snapshots the two
     vectors on the caller's stream and hands the copy to a side stream for the SUM all-reduce, so
     the next rollout launch is not ordered behind the collective; `wait` returns the reduced
-    vectors on the host.  With one process (or CPU tensors, the gloo tests) it degenerates to a
-    copy.  One collective in flight at a time."""
+    vectors on the host.  With one process there is no collective and nothing to keep off the
+    caller's stream: the vectors go to pinned host memory by one copy on that stream (ordered
+    after the launches before it and before those after it, so it is a snapshot all the same) --
+    the region bench.py times ends with this call, and two clones, a stream hand-over and two copies
+    were 50 us of it.  With CPU tensors (the gloo tests) it degenerates to a copy.  One reduction in
+    flight at a time."""
 
     def __init__(self, device=None, group=None):
         self.group = group
@@ -100,9 +114,10 @@ class StatsAllReduce:
         self.side = torch.cuda.Stream(self.device) if on_gpu else None
         self._si = self._sf = None
         self._done = None
-        # the reduced vectors land in pinned host memory on the side stream: wait() is one event wait
-        self._host_i = torch.zeros(N.NSTAT_I, dtype=torch.int64).pin_memory() if on_gpu else None
-        self._host_f = torch.zeros(N.NSTAT_F, dtype=torch.float64).pin_memory() if on_gpu else None
+        # the reduced vectors land in pinned host memory: wait() is one event wait
+        self._host = torch.zeros((N.NSTAT_I + N.NSTAT_F) * 8, dtype=torch.uint8).pin_memory() if on_gpu else None
+        self._host_i = self._host[:N.NSTAT_I * 8].view(torch.int64) if on_gpu else None
+        self._host_f = self._host[N.NSTAT_I * 8:].view(torch.float64) if on_gpu else None
 
     def start(self, stats_i: torch.Tensor, stats_f: torch.Tensor) -> None:
         if stats_i.numel() != N.NSTAT_I or stats_f.numel() != N.NSTAT_F:
@@ -115,16 +130,35 @@ class StatsAllReduce:
                 dist.all_reduce(self._sf, op=dist.ReduceOp.SUM, group=self.group)
             return
         main = torch.cuda.current_stream(self.device)
-        self._si, self._sf = stats_i.clone(), stats_f.clone()      # snapshot, ordered on `main`
+        packed = _packed(stats_i, stats_f)
+        if not multi:                                  # no collective: copy out on the caller's stream
+            if packed is not None:
+                self._host.copy_(packed, non_blocking=True)
+            else:
+                self._host_i.copy_(stats_i, non_blocking=True)
+                self._host_f.copy_(stats_f, non_blocking=True)
+            self._si = self._sf = stats_i                # marks a reduction in flight
+            self._done = torch.cuda.Event()
+            self._done.record(main)
+            return
+        if packed is not None:                         # snapshot, ordered on `main`: one clone for both
+            snap = packed.clone()
+            self._si, self._sf = snap[:N.NSTAT_I * 8].view(torch.int64), snap[N.NSTAT_I * 8:].view(torch.float64)
+        else:
+            snap = None
+            self._si, self._sf = stats_i.clone(), stats_f.clone()
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
-            if multi:
-                dist.all_reduce(self._si, op=dist.ReduceOp.SUM, group=self.group)
-                dist.all_reduce(self._sf, op=dist.ReduceOp.SUM, group=self.group)
-            self._host_i.copy_(self._si, non_blocking=True)
-            self._host_f.copy_(self._sf, non_blocking=True)
-            self._si.record_stream(self.side)
-            self._sf.record_stream(self.side)
+            dist.all_reduce(self._si, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self._sf, op=dist.ReduceOp.SUM, group=self.group)
+            if snap is not None:
+                self._host.copy_(snap, non_blocking=True)
+                snap.record_stream(self.side)
+            else:
+                self._host_i.copy_(self._si, non_blocking=True)
+                self._host_f.copy_(self._sf, non_blocking=True)
+                self._si.record_stream(self.side)
+                self._sf.record_stream(self.side)
             self._done = torch.cuda.Event()
             self._done.record(self.side)
 
