@@ -10,4 +10,4 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 echo "== single-step kernels"
 timeout -k 10 200 python3 tools/exp_env_step.py > "$OUT/env_step.jsonl" 2> /dev/null; grep '"boards_per_thread": "default"' "$OUT/env_step.jsonl"
 echo "== fuzz parity, seed 5"
-timeout -k 10 500 python3 tools/fuzz_parity.py 5 16 > "$OUT/fuzz.log" 2>&1; echo "rc=$?"; tail -n 3 "$OUT/fuzz.log" | cut -c1-300
+timeout -k 10 500 python3 tests/fuzz_parity.py 5 16 > "$OUT/fuzz.log" 2>&1; echo "rc=$?"; tail -n 3 "$OUT/fuzz.log" | cut -c1-300

@@ -13,7 +13,7 @@ timeout -k 10 500 python3 tools/exp_learning_ab.py --num-envs 1048576 --episodes
 echo "rc=$rc"; cut -c1-700 "$OUT/learning_ab_1m.jsonl"
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
 echo "== oracle thread scaling (host only)"
-timeout -k 10 300 python3 tools/exp_cpu_mt.py > "$OUT/cpu_mt.jsonl" 2> "$OUT/cpu_mt.err"; echo "rc=$?"; cat "$OUT/cpu_mt.jsonl"
+timeout -k 10 300 python3 tests/cpu_baseline_threads.py > "$OUT/cpu_mt.jsonl" 2> "$OUT/cpu_mt.err"; echo "rc=$?"; cat "$OUT/cpu_mt.jsonl"
 echo "== one-env adapters"
 timeout -k 10 200 python3 tools/exp_adapters.py > "$OUT/adapters.json" 2> "$OUT/adapters.err"; echo "rc=$?"; cat "$OUT/adapters.json"
 echo "== deterministic mode"
