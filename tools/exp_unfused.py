@@ -14,11 +14,13 @@ pkg = importlib.import_module("2048_q-learning_amd")
 TD_BITS = int(os.environ.get("UNFUSED_TD_BITS", "0"), 0)      # measurement build: write mode of k_q_update (2 << 8 = sc1)
 if TD_BITS:
     pkg._native.use_experiments_build()
+N_BOARD = int(os.environ.get("UNFUSED_BOARD_SIZE", "4"))     # 5: the 5x5 geometry
 dev = torch.device("cuda:0")
 for B in (1 << 20, 1 << 16):
-    env = pkg.BatchedGame2048Env(B, seed=0, device=dev)
+    env = pkg.BatchedGame2048Env(B, board_size=N_BOARD, seed=0, device=dev)
     agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99, exploration_rate=0.95,
-                                      capacity_log2=32 if B == 1 << 20 else 28, seed=0, device=dev, placement="plain")
+                                      capacity_log2=32 if B == 1 << 20 else 28, seed=0, device=dev, placement="plain",
+                                      board_size=N_BOARD)
     agent.fused_rollout(env, 256, play_only=True)
     agent.flags |= TD_BITS
 
@@ -39,7 +41,7 @@ for B in (1 << 20, 1 << 16):
     steps = 64
     e0.record(); loop(steps); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    print(json.dumps({"api": "4-call (choose, step, update, reset)", "B": B, "steps": steps,
+    print(json.dumps({"api": "4-call (choose, step, update, reset)", "B": B, "board": N_BOARD, "steps": steps,
                       "us_per_step": round(ms * 1e3 / steps, 1), "env_steps_per_s": B * steps / ms * 1e3}), flush=True)
     agent.ctr = env.ctr
     agent.stats_i = keep_stats
