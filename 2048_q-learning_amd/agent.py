@@ -9,6 +9,7 @@ throughput entry point (whole loop body of Agent/main.py:91-101 in one launch).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -136,6 +137,12 @@ class _ChunkedTable:
         return t
 
 
+def _ranks_on_this_device() -> int:
+    """How many ranks of this job run on each GPU (1 on a real multi-GPU node)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return max(1, -(-world // max(torch.cuda.device_count(), 1)))
+
+
 def place_table(capacity_log2: int, device: torch.device, placement="auto"):
     """Allocate the zeroed table where scattered writes run fast.
 
@@ -169,12 +176,20 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto"):
         # up to four candidates when the device has the room: chunked tables differ less than hipMalloc'd
         # ones, but on some boxes every second one still probes 10-15 % slower than the rest (57-59 against
         # 49-51 us on 2^28 and 2^30 slots); each candidate costs its mapping + zero-fill (~0.3 s for 32 GiB)
+        # (ranks that share one device -- rehearsals of a multi-GPU job on a one-GPU box -- share its free memory)
         free, _ = torch.cuda.mem_get_info(device)
-        tries = int(max(1, min(4, (0.5 * free) // nbytes)))
+        tries = int(max(1, min(4, (0.5 * free / _ranks_on_this_device()) // nbytes)))
         tables, times = [], []
         for _ in range(tries):
-            tables.append(_ChunkedTable(capacity_log2, device).tensor(device))
-            times.append(_probe_us(tables[-1], capacity_log2, device))
+            try:
+                t = _ChunkedTable(capacity_log2, device).tensor(device)
+            except N.NativeError:
+                if not tables:
+                    raise
+                break                                   # the memory went elsewhere meanwhile: keep what there is
+            tables.append(t)
+            times.append(_probe_us(t, capacity_log2, device))
+            del t
         chosen = int(np.argmin(times))
         table = tables[chosen]
         del tables
