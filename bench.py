@@ -18,7 +18,9 @@ Protocol, per rank:
   2. W warm-up steps of the real loop (table warm, RCCL initialised), untimed;
   3. the K-step region, timed `--repeats` times back to back on the same run (each region =
      ceil(K / steps_per_launch) launches + the statistics all-reduce, bracketed by barrier +
-     synchronize; MAX over ranks): the MEDIAN region is the one reported.  Every region must
+     synchronize -- the closing barrier is that all-reduce, a collective over all ranks that nobody
+     passes before every rank's steps are in; MAX over ranks): the MEDIAN region is the one
+     reported.  Every region must
      finish episodes (`stats.episodes > 0`), or the reset / terminal-row path was not measured.
 Boards, aux records and the hash Q-table are resident in HBM throughout.  Rank 0 prints ONE
 JSON line.
@@ -266,9 +268,11 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
         reducer.start(agent.stats_i, agent.stats_f)  # the path's only collective, on its own stream
         si, sf = reducer.wait()
         torch.cuda.synchronize(dev)
-        pkg.dist.barrier()
-        torch.cuda.synchronize(dev)
+        # The closing barrier of the region is the reduction itself -- a collective over all ranks: nobody
+        # gets past it before every rank's K steps are in -- followed by synchronize.  MAX over ranks below.
         wall = time.perf_counter() - t0
+        pkg.dist.barrier()                           # (a second, explicit one: outside the clock)
+        torch.cuda.synchronize(dev)
         st = pkg.stats_dict(si, sf)                  # all-reduced: whole-job numbers
         total = shard.total_envs * steps
         assert st["steps"] == total, (st["steps"], total)
