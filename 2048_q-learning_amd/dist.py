@@ -87,13 +87,15 @@ def allreduce_stats(stats_i: torch.Tensor, stats_f: torch.Tensor, group=None):
 
 
 def _packed(stats_i: torch.Tensor, stats_f: torch.Tensor):
-    """The uint8 buffer both vectors are views of (agent.new_stats_vectors), or None."""
-    base = stats_i._base
-    if (base is None or base is not stats_f._base or base.dtype != torch.uint8 or base.dim() != 1
-            or base.numel() != (N.NSTAT_I + N.NSTAT_F) * 8 or not base.is_contiguous()
-            or stats_i.data_ptr() != base.data_ptr() or stats_f.data_ptr() != base.data_ptr() + N.NSTAT_I * 8):
+    """One uint8 tensor over both vectors when they are the two halves of one allocation
+    (agent.new_stats_vectors), or None."""
+    total = (N.NSTAT_I + N.NSTAT_F) * 8
+    st = stats_i.untyped_storage()
+    if (st.data_ptr() != stats_f.untyped_storage().data_ptr() or st.nbytes() != total
+            or stats_i.storage_offset() != 0 or stats_f.storage_offset() != N.NSTAT_I
+            or not stats_i.is_contiguous() or not stats_f.is_contiguous()):
         return None
-    return base
+    return torch.empty(0, dtype=torch.uint8, device=stats_i.device).set_(st, 0, (total,))
 
 
 class StatsAllReduce:

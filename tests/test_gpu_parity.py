@@ -1872,6 +1872,31 @@ def test_bench_under_torchrun_one_rank_drives_rccl():
     assert "RCCL" in rec["config"]["parallelism"] and rec["stats"]["status"] == 0
 
 
+@pytest.mark.gpu
+def test_stats_reduction_on_the_device_is_a_snapshot(pkg):
+    """StatsAllReduce with one process: the vectors reach the host by one copy when they are the two
+    views of an agent's buffer, by two when they are separate tensors -- either way what `wait` returns
+    is what the vectors held when `start` was called, whatever is launched after it."""
+    N = pkg._native
+    r = pkg.StatsAllReduce(DEV)
+    agent = pkg.BatchedQLearningAgent(10, capacity_log2=10, seed=1, device=DEV)
+    assert pkg.dist._packed(agent.stats_i, agent.stats_f) is not None        # one copy
+    for si, sf in ((agent.stats_i, agent.stats_f),
+                   (torch.zeros(N.NSTAT_I, dtype=torch.int64, device=DEV),
+                    torch.zeros(N.NSTAT_F, dtype=torch.float64, device=DEV))):
+        assert (pkg.dist._packed(si, sf) is None) == (si is not agent.stats_i)
+        si.copy_(torch.arange(N.NSTAT_I, dtype=torch.int64))
+        sf.fill_(2.5)
+        r.start(si, sf)
+        si.add_(1000)                                      # after the snapshot, on the same stream
+        sf.zero_()
+        a, b = r.wait()
+        assert a.tolist() == list(range(N.NSTAT_I)) and b.tolist() == [2.5] * N.NSTAT_F
+        assert int(si[3]) == 1003
+    with pytest.raises(RuntimeError):
+        r.wait()
+
+
 # ---------------------------------------------------------------------------------------------
 # evaluation of a trained table (the reference README's evaluate.py / models/)
 # ---------------------------------------------------------------------------------------------
