@@ -848,11 +848,14 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
         if (slot < 0 && slot != kNoSlot) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
       }
       // q_table[next_state] (:41), created when absent as well; an invalid move stays on the row of s
+      // The claim of an absent s' is issued here and its answer read after the TD write of s, which
+      // does not depend on it: one round trip less on the lane's chain (4x4; 5x5 claims in place).
       Row rn = rs;
       int64_t slot_n = slot;
+      Claim claim{0ull, 0ull, false};
       if (!same) {
         slot_n = probe_find(table, mask, key_n, rn, ins_n);
-        if (slot_n < 0 && slot_n != kNoSlot) slot_n = probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
+        slot_n = claim_issue(table, mask, slot_n, key_n, claim, ins_n);
       }
       const float max_next = max4(rn.q0, rn.q1, rn.q2, rn.q3);
       if (slot >= 0) {
@@ -863,6 +866,9 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
         dropped = true;
         atomicOr(status, Q2048_STATUS_TABLE_FULL);
       }
+      bool ins_c = false;
+      slot_n = claim_resolve(table, mask, key_n, claim, slot_n, ins_c);
+      ins_n = ins_n || ins_c;
       if (cache != nullptr) cache_put(cache, i, key_n, rn, slot_n);
     }
     const uint32_t n_ins = wave_count(ins_n) + wave_count(ins_s), n_drop = wave_count(dropped);
@@ -886,18 +892,21 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
 // reference's defaultdict creates them (q_table[next_state] / q_table[state] in
 // update_q_value, Agent/main.py:41-43).
 // ---------------------------------------------------------------------------------------------
-// Waves per SIMD the register allocator must leave room for.  6 (<= 80 VGPRs, 5 dwords of
-// scratch) measures +2 % over the unconstrained 88 VGPRs / 5 waves; 7 and 8 spill more than the
-// extra waves hide (-9 %, -17 %).
-#ifndef Q2048_FUSED_MIN_WAVES
-#define Q2048_FUSED_MIN_WAVES 6
+// Waves per SIMD the register allocator must leave room for.  4x4: 6 (<= 80 VGPRs, 9 dwords of
+// scratch, two 8-byte reloads per step) measures 42.4 us per 1 Mi-board step against 43.0 / 43.3 at
+// 4 / 5 waves; 7 and 8 spill more than the extra waves hide (49.1, 55.3).  5x5: 5 (96 VGPRs, no
+// scratch in the step loop) measures 1 % over 6 (profiles/r03_launch_cost.txt).
+#ifdef Q2048_FUSED_MIN_WAVES                       // measurement builds: one value for both geometries
+#define Q2048_FUSED_WAVES(N) Q2048_FUSED_MIN_WAVES
+#else
+#define Q2048_FUSED_WAVES(N) ((N) == 4 ? 6 : 5)
 #endif
 // MODE: what the launch does with the table -- a template parameter, so the step loop carries no
 // run-time mode tests (kModeLearn: plain-store TD; kModeCas: Q2048_FLAG_TD_CAS; kModeEval:
 // Q2048_FLAG_NO_LEARN; play-only is an ENV bit).  Experiment builds select write modes at run time.
 constexpr int kModeLearn = 0, kModeCas = 1, kModeEval = 2;
 template <int N, int ENV, int MODE>
-__global__ __launch_bounds__(kBlock, Q2048_FUSED_MIN_WAVES) void k_fused_rollout(
+__global__ __launch_bounds__(kBlock, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
     double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
     int64_t* stats_i, double* stats_f, uint32_t* status, q2048_episode* log, int64_t log_cap,
