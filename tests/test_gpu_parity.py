@@ -1131,6 +1131,47 @@ def test_full_size_1m_lanes_q_dependent_actions(pkg, O, n, cap):
     assert agent.check_status() == 0 and pkg._native.claim_timeouts() == 0
 
 
+def test_full_size_1m_lanes_four_call_api(pkg, O):
+    """The reference's four calls (choose_action, step, update_q_value, reset(done); no board copy, row
+    cache) at 1,048,576 lanes with private rows (Q2048_FLAG_INDEPENDENT) and eps = 0.2: 400 sampled lanes
+    against one oracle agent each -- boards and aux bit-exact, every Q row of the lane within rtol 1e-5.
+    (`k_q_update` issues the claim of s' before the TD write of s and reads its answer afterwards: this is
+    that kernel at the bench's size, 0.65 claims per lane-step in flight at once.)"""
+    B, seed, id0, eps, lr, gamma, steps = 1 << 20, 77, 5, 0.2, 0.1, 0.99, 40
+    env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(1000, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                      capacity_log2=27, seed=seed, env_id0=id0, device=DEV, independent=True)
+    s = env.boards
+    for _ in range(steps):
+        a = agent.choose_action(s)
+        s2, r, d, _ = env.step(a)                       # the other board buffer: `s` stays intact
+        agent.update_q_value(s, a, r, s2, d)
+        s = env.reset(d)
+    boards = env.boards.cpu().numpy()
+    aux = env.aux_fields()
+    rng = np.random.default_rng(9)
+    sample = np.unique(np.concatenate([[0, 63, 64, 1023, 1024, B - 1025, B - 1], rng.integers(0, B, size=400)]))
+    worst, rows = 0.0, 0
+    for i in sample.tolist():
+        envs = O.envs_init(1, 4, seed, id0 + i)
+        oa = O.Agent(1000, 4, lr, gamma, eps)
+        O.rollout(envs, oa, steps, seed, id0 + i, 0)
+        assert boards[i].tolist() == envs["board"][0, :16].tolist(), i
+        assert aux["score"][i] == envs["score"][0] and aux["episode"][i] == envs["episode"][0], i
+        assert aux["cons_count"][i] == envs["consecutive_count"][0], i
+        keys, vals = oa.dump()
+        got, found = agent.q_values(t8(keys), env_id=id0 + i, return_found=True)
+        assert bool(found.all()), i
+        got = got.cpu().numpy()
+        assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), i
+        worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
+        rows += len(keys)
+    print(f"[q] 4-call API, 1M lanes: {len(sample)} lanes, {rows} rows, worst relative Q error {worst:.2e}")
+    st = agent.stats()
+    assert st["drops"] == 0 and st["inserts"] == agent.table_size()
+    assert agent.check_status() == 0 and pkg._native.claim_timeouts() == 0
+
+
 def test_table_full_drops_are_counted_not_raised(pkg, O):
     """A table that is too small: updates are dropped and counted, the status word says so,
     nothing raises, and the env trajectories are untouched."""
