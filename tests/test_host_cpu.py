@@ -403,6 +403,37 @@ def test_bench_self_launches_its_ranks_and_propagates_failure():
     assert "no HIP device" in p.stderr or "MI355X" in p.stderr
 
 
+def test_statistics_vectors_share_one_buffer(pkg, monkeypatch):
+    """agent.new_stats_vectors: the int64 and the float64 vector are the two halves of one allocation,
+    which dist._packed recognises (one copy / one clone for both) and separate tensors are not; ranks
+    that share a device divide its free memory among them when candidate tables are sized."""
+    import importlib
+
+    import torch
+
+    agent_mod = importlib.import_module("2048_q-learning_amd.agent")
+    dist_mod = importlib.import_module("2048_q-learning_amd.dist")
+    n = pkg._native
+    si, sf = agent_mod.new_stats_vectors("cpu")
+    assert si.dtype == torch.int64 and sf.dtype == torch.float64
+    assert si.numel() == n.NSTAT_I and sf.numel() == n.NSTAT_F
+    raw = dist_mod._packed(si, sf)
+    assert raw is not None and raw.numel() == 8 * (n.NSTAT_I + n.NSTAT_F)
+    si[3] = 7
+    sf[1] = 2.5
+    assert int(raw[24:32].view(torch.int64)) == 7
+    assert float(raw[8 * n.NSTAT_I + 8:8 * n.NSTAT_I + 16].view(torch.float64)) == 2.5
+    assert dist_mod._packed(torch.zeros(n.NSTAT_I, dtype=torch.int64), torch.zeros(n.NSTAT_F, dtype=torch.float64)) is None
+    assert dist_mod._packed(si.clone(), sf) is None
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert agent_mod._ranks_on_this_device() == 4
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert agent_mod._ranks_on_this_device() == 1
+    monkeypatch.delenv("WORLD_SIZE")
+    assert agent_mod._ranks_on_this_device() == 1
+
+
 def test_stats_allreduce_object_single_process(pkg):
     import torch
 
