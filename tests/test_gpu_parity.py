@@ -1131,16 +1131,18 @@ def test_full_size_1m_lanes_q_dependent_actions(pkg, O, n, cap):
     assert agent.check_status() == 0 and pkg._native.claim_timeouts() == 0
 
 
-def test_full_size_1m_lanes_four_call_api(pkg, O):
+@pytest.mark.parametrize("n", [4, 5])
+def test_full_size_1m_lanes_four_call_api(pkg, O, n):
     """The reference's four calls (choose_action, step, update_q_value, reset(done); no board copy, row
     cache) at 1,048,576 lanes with private rows (Q2048_FLAG_INDEPENDENT) and eps = 0.2: 400 sampled lanes
     against one oracle agent each -- boards and aux bit-exact, every Q row of the lane within rtol 1e-5.
     (`k_q_update` issues the claim of s' before the TD write of s and reads its answer afterwards: this is
     that kernel at the bench's size, 0.65 claims per lane-step in flight at once.)"""
     B, seed, id0, eps, lr, gamma, steps = 1 << 20, 77, 5, 0.2, 0.1, 0.99, 40
-    env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
     agent = pkg.BatchedQLearningAgent(1000, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
-                                      capacity_log2=27, seed=seed, env_id0=id0, device=DEV, independent=True)
+                                      capacity_log2=27, seed=seed, env_id0=id0, device=DEV, independent=True,
+                                      board_size=n)
     s = env.boards
     for _ in range(steps):
         a = agent.choose_action(s)
@@ -1153,10 +1155,10 @@ def test_full_size_1m_lanes_four_call_api(pkg, O):
     sample = np.unique(np.concatenate([[0, 63, 64, 1023, 1024, B - 1025, B - 1], rng.integers(0, B, size=400)]))
     worst, rows = 0.0, 0
     for i in sample.tolist():
-        envs = O.envs_init(1, 4, seed, id0 + i)
-        oa = O.Agent(1000, 4, lr, gamma, eps)
+        envs = O.envs_init(1, n, seed, id0 + i)
+        oa = O.Agent(1000, 4, lr, gamma, eps, n=n)
         O.rollout(envs, oa, steps, seed, id0 + i, 0)
-        assert boards[i].tolist() == envs["board"][0, :16].tolist(), i
+        assert boards[i].tolist() == envs["board"][0, :n * n].tolist(), i
         assert aux["score"][i] == envs["score"][0] and aux["episode"][i] == envs["episode"][0], i
         assert aux["cons_count"][i] == envs["consecutive_count"][0], i
         keys, vals = oa.dump()
@@ -1166,7 +1168,7 @@ def test_full_size_1m_lanes_four_call_api(pkg, O):
         assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), i
         worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
         rows += len(keys)
-    print(f"[q] 4-call API, 1M lanes: {len(sample)} lanes, {rows} rows, worst relative Q error {worst:.2e}")
+    print(f"[q] 4-call API, {n}x{n}, 1M lanes: {len(sample)} lanes, {rows} rows, worst relative Q error {worst:.2e}")
     st = agent.stats()
     assert st["drops"] == 0 and st["inserts"] == agent.table_size()
     assert agent.check_status() == 0 and pkg._native.claim_timeouts() == 0
