@@ -24,12 +24,23 @@ OK = 0
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
 FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
 FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY, FLAG_NO_LEARN = 8, 16, 32, 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
 ST_HIST0, NSTAT_I = 8, 32
 ST_HIST_BINS, ST_CAS_FALLBACK = 23, 31
 SF_RETURN, SF_RETURN_SQ, SF_REWARD, NSTAT_F = 0, 1, 2, 4
 SIZEOF_AUX, SIZEOF_SLOT, SIZEOF_EPISODE = 16, 32, 48
+MIRROR_SEQ, MIRROR_WORDS = NSTAT_I + NSTAT_F, NSTAT_I + NSTAT_F + 1
+
+
+class RolloutOpts(C.Structure):
+    """q2048_rollout_opts (include/q2048.h): the optional extras of q2048_fused_rollout_opts."""
+    _fields_ = [("size", C.c_uint32), ("reserved", C.c_uint32), ("log", C.c_void_p),
+                ("log_capacity", C.c_int64), ("log_count", C.c_void_p), ("row_cache", C.c_void_p),
+                ("stats_mirror", C.c_void_p), ("mirror_ticket", C.c_void_p)]
+
+    def __init__(self, **kw):
+        super().__init__(size=C.sizeof(RolloutOpts), **kw)
 
 
 class NativeError(RuntimeError):
@@ -136,6 +147,10 @@ _SIGNATURES = {
                                           C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_void_p]),
+    "q2048_fused_rollout_opts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                           C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                           C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.POINTER(RolloutOpts), C.c_void_p]),
     "q2048_table_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "q2048_table_free": (C.c_int, [C.c_void_p]),
     "q2048_table_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_void_p]),

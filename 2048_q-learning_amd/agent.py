@@ -278,6 +278,12 @@ class BatchedQLearningAgent:
         self.q_table = _QTableView(self)
         self.row_cache_enabled = bool(row_cache)
         self._row_cache = None
+        # statistics mirror of the fused rollout: the launch's last block copies both vectors into pinned
+        # host memory the kernels address directly (q2048_rollout_opts.stats_mirror)
+        self._mirror = torch.zeros(N.MIRROR_WORDS, dtype=torch.int64).pin_memory()
+        self._mirror_np = self._mirror.numpy()
+        self._mirror_ticket = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._mirror_launches = 0
 
     def _cache(self, B: int):
         """The row cache for a batch of B envs (device pointer or None)."""
@@ -370,18 +376,35 @@ class BatchedQLearningAgent:
         if env.ctr != self.ctr:
             raise ValueError(f"env.ctr={env.ctr} and agent.ctr={self.ctr} are out of step")
         log = episode_log
-        self.invalidate_row_cache()
-        N.check(N.lib().q2048_fused_rollout_log(
+        # the row every env carries goes from launch to launch (and to choose_action / update_q_value)
+        # through the row cache; a learner-less launch touches neither the table nor the cache
+        cache = None if play_only else self._cache(env.num_envs)
+        opts = N.RolloutOpts(
+            log=_ptr(log.records) if log is not None else None, log_capacity=log.capacity if log is not None else 0,
+            log_count=_ptr(log.count) if log is not None else None, row_cache=_ptr(cache),
+            stats_mirror=self._mirror.data_ptr(), mirror_ticket=_ptr(self._mirror_ticket))
+        N.check(N.lib().q2048_fused_rollout_opts(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
             self.board_size, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
             self.env_id0, self.ctr & 0xFFFFFFFF,
             self.flags | self.experiment_bits | env.env_flags | (N.FLAG_PLAY_ONLY if play_only else 0) |
             (0 if learn else N.FLAG_NO_LEARN),
-            _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status),
-            _ptr(log.records) if log is not None else None, log.capacity if log is not None else 0,
-            _ptr(log.count) if log is not None else None, _stream(self.device)), "fused_rollout")
+            _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status), C.byref(opts), _stream(self.device)),
+            "fused_rollout")
+        if env.num_envs > 0 and int(steps) > 0:
+            self._mirror_launches += 1
         env.ctr += int(steps)
         self.ctr += int(steps)
+
+    def mirrored_stats(self):
+        """(stats_i, stats_f) as the last `fused_rollout` launch left them, read from the host-side
+        mirror its last block wrote -- no device call, no copy: valid once the caller has waited for that
+        launch (stream / event / device synchronize).  Raises if the mirror is not that launch's."""
+        m = self._mirror_np
+        if int(m[N.MIRROR_SEQ]) & 0xFFFFFFFF != self._mirror_launches & 0xFFFFFFFF:
+            raise RuntimeError(f"statistics mirror holds launch {int(m[N.MIRROR_SEQ])}, expected "
+                               f"{self._mirror_launches}: wait for the launch before reading it")
+        return m[:N.NSTAT_I].copy(), m[N.NSTAT_I:N.NSTAT_I + N.NSTAT_F].view(np.float64).copy()
 
     def deterministic_rollout(self, env: BatchedGame2048Env, steps: int) -> None:
         """Reproducible shared-table training (q2048_det_rollout): per step every env acts on the

@@ -45,6 +45,7 @@ static_assert(sizeof(q2048_aux) == 16 && sizeof(q2048_slot) == 32, "ABI layout")
 static_assert(sizeof(q2048_episode) == 48, "ABI layout");
 static_assert(offsetof(q2048_slot, q) == 8 && offsetof(q2048_slot, reserved) == 24, "ABI layout");
 static_assert(sizeof(Aux) == sizeof(q2048_aux), "core/ABI aux mismatch");
+static_assert(Q2048_MIRROR_SEQ == Q2048_NSTAT_I + Q2048_NSTAT_F && Q2048_MIRROR_WORDS == Q2048_MIRROR_SEQ + 1, "ABI layout");
 
 using u64 = unsigned long long;
 
@@ -495,6 +496,42 @@ __global__ __launch_bounds__(64) void k_stats_fold(const StatStripe* stripes, in
     if (sum != 0.0) atomicAdd(gf + (t - Q2048_NSTAT_I), sum);
   }
 }
+// Statistics mirror (optional, fused rollout): the LAST block of a launch to finish copies the two
+// statistics vectors, as they stand after every block's flush, into `mirror` -- a buffer the HOST can
+// read (pinned host memory mapped into the device's address space) -- so a caller that waits for the
+// launch anyway needs no device-to-host copy behind it (a 288-byte copy queued on the stream cost the
+// bench's 1 ms region 15-18 us, profiles/r03_region_overhead.txt).  "Last" is decided by a ticket:
+// every block, after its own statistics atomics have been acknowledged (agent-scope release fence),
+// takes a number; the block that draws gridDim.x - 1 knows all the others are in, reads the vectors
+// at the memory side (agent-scope loads: the adds were device-scope atomics, no L2 holds anything
+// newer) and writes them out with system-scope stores, followed by the number of mirrored launches so
+// far (ticket[1], mirror[Q2048_MIRROR_SEQ]: how the host tells a fresh mirror from the last one), and
+// resets the ticket for the next launch.  ticket = device uint32[2], zero before its first use.
+__device__ __forceinline__ void stats_mirror(const int64_t* gi, const double* gf, u64* mirror, uint32_t* ticket) {
+  if (mirror == nullptr) return;                          // (uniform over the grid)
+  __shared__ uint32_t my_ticket;
+  __threadfence();                                        // this thread's statistics atomics are performed
+  __syncthreads();
+  if (threadIdx.x == 0) my_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (my_ticket != gridDim.x - 1u) return;
+  __threadfence();
+  const int t = (int)threadIdx.x;
+  if (t < Q2048_NSTAT_I + Q2048_NSTAT_F) {
+    const u64* src = t < Q2048_NSTAT_I ? reinterpret_cast<const u64*>(gi) + t
+                                       : reinterpret_cast<const u64*>(gf) + (t - Q2048_NSTAT_I);
+    const u64 v = __hip_atomic_load(const_cast<u64*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mirror + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) {
+    const uint32_t launches = ticket[1] + 1u;             // only ever touched here, by one thread per launch
+    ticket[1] = launches;
+    __hip_atomic_store(mirror + Q2048_MIRROR_SEQ, (u64)launches, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 __device__ __forceinline__ void episode_stats(BlockStats& s, const Aux& a, uint32_t max_l2) {
   atomicAdd(&s.i[Q2048_ST_SCORE], (u64)(int64_t)a.score);
   atomicAdd(&s.i[Q2048_ST_HIST0 + (max_l2 > 22u ? 22u : max_l2)], 1ull);
@@ -910,7 +947,8 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
     double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
     int64_t* stats_i, double* stats_f, uint32_t* status, q2048_episode* log, int64_t log_cap,
-    u64* log_count) {
+    u64* log_count, void* row_cache, u64* mirror, uint32_t* ticket) {
+  RowCache<N>* const cache = static_cast<RowCache<N>*>(row_cache);
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
   stats_clear(bs);
@@ -941,7 +979,12 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     auto key_s = state_key(b, salt, status);
     Row q{0.f, 0.f, 0.f, 0.f};
     bool made0 = false;
-    int64_t slot_s = play_only ? kNoSlot : probe_find(table, mask, key_s, q, made0);
+    // The row the launch starts in: what this env's last launch (or update_q_value) left in the row
+    // cache when the board is still the one it left -- a coalesced 32-byte read -- else a probe (one
+    // scattered 128-byte request per lane: 21.5 us of every launch at 1 Mi boards)
+    int64_t slot_s = kNoSlot;
+    if (!play_only && (cache == nullptr || !cache_get(cache, i, key_s, q, slot_s)))
+      slot_s = probe_find(table, mask, key_s, q, made0);
     Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
     uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = wave_count(made0), n_drop = 0;
@@ -1029,9 +1072,12 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     }
     if (pend && slot_s >= 0) flush_pending(&table[slot_s], q, pend);
     bool ins_last = false;  // the claim issued by the last step (its row belongs to the dict too)
-    claim_resolve(table, mask, key_s, claim, slot_s, ins_last);
+    slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_last);
     n_insert += wave_count(ins_last);
     st_aux(aux, i, a);
+    // hand the carried row to this env's next launch / choose_action / update_q_value (a state whose
+    // row does not exist yet -- an episode began on the last step -- leaves an empty record)
+    if (!play_only && cache != nullptr) cache_put(cache, i, key_s, q, slot_s);
 
     if (n_drop) atomicOr(status, Q2048_STATUS_TABLE_FULL);
     if (tdc.retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)tdc.retries);
@@ -1049,6 +1095,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
   }
   store_board(boards, i, B, b, st);
   stats_flush(bs, stats_i, stats_f);
+  stats_mirror(stats_i, stats_f, mirror, ticket);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2039,9 +2086,8 @@ int q2048_fused_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int 
                         int n, int64_t steps, double eps, double lr, double gamma, uint64_t seed,
                         uint64_t env_id0, uint32_t ctr0, uint32_t flags, int64_t* stats_i,
                         double* stats_f, uint32_t* status, void* stream) {
-  return q2048_fused_rollout_log(boards, aux, table, cap_log2, B, n, steps, eps, lr, gamma, seed,
-                                 env_id0, ctr0, flags, stats_i, stats_f, status, nullptr, 0, nullptr,
-                                 stream);
+  return q2048_fused_rollout_opts(boards, aux, table, cap_log2, B, n, steps, eps, lr, gamma, seed,
+                                  env_id0, ctr0, flags, stats_i, stats_f, status, nullptr, stream);
 }
 
 int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2,
@@ -2049,10 +2095,32 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
                             uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
                             int64_t* stats_i, double* stats_f, uint32_t* status, q2048_episode* log,
                             int64_t log_capacity, uint64_t* log_count, void* stream) {
+  q2048_rollout_opts o = {};
+  o.size = (uint32_t)sizeof(o);
+  o.log = log; o.log_capacity = log_capacity; o.log_count = log_count;
+  return q2048_fused_rollout_opts(boards, aux, table, cap_log2, B, n, steps, eps, lr, gamma, seed,
+                                  env_id0, ctr0, flags, stats_i, stats_f, status, &o, stream);
+}
+
+int q2048_fused_rollout_opts(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2,
+                             int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
+                             uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
+                             int64_t* stats_i, double* stats_f, uint32_t* status,
+                             const q2048_rollout_opts* opts, void* stream) {
+  q2048_rollout_opts o = {};
+  if (opts != nullptr) {
+    if (opts->size != sizeof(q2048_rollout_opts)) return Q2048_ERR_SIZE;   // a caller built against another header
+    o = *opts;
+  }
   if (int e = check_batch(B, n)) return e;
   if (int e = check_flags(flags)) return e;
-  if (log != nullptr && (log_count == nullptr || log_capacity < 0)) return Q2048_ERR_NULL;
-  if (log != nullptr && !aligned16(log)) return Q2048_ERR_ALIGN;
+  if (o.log != nullptr && (o.log_count == nullptr || o.log_capacity < 0)) return Q2048_ERR_NULL;
+  if (o.log != nullptr && !aligned16(o.log)) return Q2048_ERR_ALIGN;
+  if (o.row_cache != nullptr && !aligned16(o.row_cache)) return Q2048_ERR_ALIGN;
+  // the mirror is a copy of both vectors, taken by the launch's last block: it needs both, and its ticket
+  if (o.stats_mirror != nullptr && (o.mirror_ticket == nullptr || stats_i == nullptr || stats_f == nullptr))
+    return Q2048_ERR_NULL;
+  if (o.stats_mirror != nullptr && (reinterpret_cast<uintptr_t>(o.stats_mirror) & 7u)) return Q2048_ERR_ALIGN;
   if (int e = check_table(table, cap_log2)) return e;
   if (!boards || !aux || !status) return Q2048_ERR_NULL;
   if (!aligned16(boards) || !aligned16(aux)) return Q2048_ERR_ALIGN;
@@ -2061,7 +2129,8 @@ int q2048_fused_rollout_log(uint8_t* boards, q2048_aux* aux, q2048_slot* table, 
   if (B == 0 || steps == 0) return Q2048_OK;
   Q2048_LAUNCH_FUSED(flags, n, B, stream, boards, aux, table,
                      (u64)((1ull << cap_log2) - 1ull), B, (int)steps, eps, lr, gamma, seed, env_id0, ctr0,
-                     flags, stats_i, stats_f, status, log, log_capacity, reinterpret_cast<u64*>(log_count));
+                     flags, stats_i, stats_f, status, o.log, o.log_capacity, reinterpret_cast<u64*>(o.log_count),
+                     o.row_cache, reinterpret_cast<u64*>(o.stats_mirror), o.mirror_ticket);
   return launch_status();
 }
 

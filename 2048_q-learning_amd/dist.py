@@ -3,9 +3,9 @@
 The reference runs one env in one process (no distributed code).  Envs are independent, so the
 batch shards embarrassingly: rank r owns a contiguous range of GLOBAL env ids, and because the
 counter RNG is keyed by the global id, every env's trajectory is independent of the world size.
-Each GPU keeps its own Q-table replica.  The only collective is a SUM all-reduce of the
-episode statistics vector (a few hundred bytes, latency-bound) over RCCL (`nccl` backend on
-ROCm) or gloo in the CPU tests."""
+Each GPU keeps its own Q-table replica.  The only collective is the reduction of the episode
+statistics vectors (288 bytes, latency-bound: one all-gather, summed on the host) over RCCL
+(`nccl` backend on ROCm) or gloo in the CPU tests."""
 from __future__ import annotations
 
 import os
@@ -99,82 +99,98 @@ def _packed(stats_i: torch.Tensor, stats_f: torch.Tensor):
 
 
 class StatsAllReduce:
-    """The statistics all-reduce on a stream of its own: `start` snapshots the two
-    vectors on the caller's stream and hands the copy to a side stream for the SUM all-reduce, so
-    the next rollout launch is not ordered behind the collective; `wait` returns the reduced
-    vectors on the host.  With one process there is no collective and nothing to keep off the
-    caller's stream: the vectors go to pinned host memory by one copy on that stream (ordered
-    after the launches before it and before those after it, so it is a snapshot all the same) --
-    the region bench.py times ends with this call, and two clones, a stream hand-over and two copies
-    were 50 us of it.  With CPU tensors (the gloo tests) it degenerates to a copy.  One reduction in
-    flight at a time."""
+    """The statistics reduction on a stream of its own -- ONE collective: `start`
+    snapshots the two vectors as one 288-byte buffer on the caller's stream and hands it to a side
+    stream for an all-gather, so the next rollout launch is not ordered behind the collective; `wait`
+    returns the SUM over ranks, added up on the host in rank order (int64 and float64 each in its own
+    type: exact counts, and a float sum that does not depend on the collective's reduction tree).
+    With one process there is no
+    collective and nothing to keep off the caller's stream: the buffer goes to pinned host memory by
+    one copy on that stream (ordered after the launches before it and before those after it, so it is
+    a snapshot all the same).  With CPU tensors (the gloo tests) it is a host all-gather.  One
+    reduction in flight at a time."""
 
     def __init__(self, device=None, group=None):
         self.group = group
         self.device = None if device is None else torch.device(device)
         on_gpu = self.device is not None and self.device.type == "cuda"
         self.side = torch.cuda.Stream(self.device) if on_gpu else None
-        self._si = self._sf = None
+        self.nbytes = (N.NSTAT_I + N.NSTAT_F) * 8
+        self._pending = False
         self._done = None
-        # the reduced vectors land in pinned host memory: wait() is one event wait
-        self._host = torch.zeros((N.NSTAT_I + N.NSTAT_F) * 8, dtype=torch.uint8).pin_memory() if on_gpu else None
-        self._host_i = self._host[:N.NSTAT_I * 8].view(torch.int64) if on_gpu else None
-        self._host_f = self._host[N.NSTAT_I * 8:].view(torch.float64) if on_gpu else None
+        self._world = 1
+        self._host = None
+        self._cpu_parts = None
+
+    def _host_buffer(self, world: int) -> torch.Tensor:
+        if self._host is None or self._host.shape[0] < world:
+            self._host = torch.zeros((world, self.nbytes), dtype=torch.uint8).pin_memory()
+        return self._host
+
+    def _pack(self, stats_i, stats_f) -> torch.Tensor:
+        """One uint8 tensor [nbytes]: stats_i | stats_f -- a fresh buffer (the snapshot)."""
+        packed = _packed(stats_i, stats_f)
+        if packed is not None:
+            return packed.clone()                      # both vectors by one copy
+        buf = torch.empty(self.nbytes, dtype=torch.uint8, device=stats_i.device)
+        buf[:N.NSTAT_I * 8].view(torch.int64).copy_(stats_i)
+        buf[N.NSTAT_I * 8:].view(torch.float64).copy_(stats_f)
+        return buf
 
     def start(self, stats_i: torch.Tensor, stats_f: torch.Tensor) -> None:
         if stats_i.numel() != N.NSTAT_I or stats_f.numel() != N.NSTAT_F:
             raise ValueError("unexpected statistics vector length")
         multi = dist.is_available() and dist.is_initialized()    # a 1-rank group still runs the collective
-        if self.side is None:
-            self._si, self._sf = stats_i.clone(), stats_f.clone()
+        world = dist.get_world_size(self.group) if multi else 1
+        self._world, self._pending = world, True
+        if self.side is None:                                    # CPU tensors (gloo tests)
+            snap = self._pack(stats_i, stats_f)
             if multi:
-                dist.all_reduce(self._si, op=dist.ReduceOp.SUM, group=self.group)
-                dist.all_reduce(self._sf, op=dist.ReduceOp.SUM, group=self.group)
+                parts = [torch.empty_like(snap) for _ in range(world)]
+                dist.all_gather(parts, snap, group=self.group)
+            else:
+                parts = [snap]
+            self._cpu_parts = torch.stack(parts)
             return
         main = torch.cuda.current_stream(self.device)
-        packed = _packed(stats_i, stats_f)
+        host = self._host_buffer(world)
         if not multi:                                  # no collective: copy out on the caller's stream
+            packed = _packed(stats_i, stats_f)
             if packed is not None:
-                self._host.copy_(packed, non_blocking=True)
+                host[0].copy_(packed, non_blocking=True)
             else:
-                self._host_i.copy_(stats_i, non_blocking=True)
-                self._host_f.copy_(stats_f, non_blocking=True)
-            self._si = self._sf = stats_i                # marks a reduction in flight
+                host[0, :N.NSTAT_I * 8].view(torch.int64).copy_(stats_i, non_blocking=True)
+                host[0, N.NSTAT_I * 8:].view(torch.float64).copy_(stats_f, non_blocking=True)
             self._done = torch.cuda.Event()
             self._done.record(main)
             return
-        if packed is not None:                         # snapshot, ordered on `main`: one clone for both
-            snap = packed.clone()
-            self._si, self._sf = snap[:N.NSTAT_I * 8].view(torch.int64), snap[N.NSTAT_I * 8:].view(torch.float64)
-        else:
-            snap = None
-            self._si, self._sf = stats_i.clone(), stats_f.clone()
+        snap = self._pack(stats_i, stats_f)            # ordered on `main`
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
-            dist.all_reduce(self._si, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(self._sf, op=dist.ReduceOp.SUM, group=self.group)
-            if snap is not None:
-                self._host.copy_(snap, non_blocking=True)
-                snap.record_stream(self.side)
-            else:
-                self._host_i.copy_(self._si, non_blocking=True)
-                self._host_f.copy_(self._sf, non_blocking=True)
-                self._si.record_stream(self.side)
-                self._sf.record_stream(self.side)
+            gathered = torch.empty((world, self.nbytes), dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(gathered.view(-1), snap, group=self.group)   # the one collective
+            host[:world].copy_(gathered, non_blocking=True)
+            snap.record_stream(self.side)
+            gathered.record_stream(self.side)
             self._done = torch.cuda.Event()
             self._done.record(self.side)
 
     def wait(self):
-        """(stats_i, stats_f) of the last `start`, all-reduced, as host numpy arrays."""
-        if self._si is None:
+        """(stats_i, stats_f) of the last `start`, summed over ranks, as host numpy arrays."""
+        if not self._pending:
             raise RuntimeError("wait() without start()")
+        self._pending = False
         if self._done is not None:
             self._done.synchronize()
             self._done = None
-            si, sf = self._host_i.numpy().copy(), self._host_f.numpy().copy()
+            parts = self._host.numpy()[:self._world]
         else:
-            si, sf = self._si.cpu().numpy(), self._sf.cpu().numpy()
-        self._si = self._sf = None
+            parts, self._cpu_parts = self._cpu_parts.numpy(), None
+        ni, nf = N.NSTAT_I * 8, N.NSTAT_F * 8
+        si = parts[:, :ni].copy().view(np.int64).sum(axis=0)
+        sf = np.zeros(N.NSTAT_F, dtype=np.float64)
+        for r in range(parts.shape[0]):                # rank order: one fixed summation order
+            sf += parts[r, ni:ni + nf].copy().view(np.float64)
         return si, sf
 
 
@@ -185,6 +201,17 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def max_over_ranks_many(values, device=None, group=None) -> list:
+    """MAX all-reduce of a list of floats in ONE collective (bench.py: every region's wall and kernel
+    time, after the last region)."""
+    values = [float(v) for v in values]
+    if not (dist.is_available() and dist.is_initialized()) or not values:
+        return values
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return [float(x) for x in t.cpu().tolist()]
 
 
 def barrier(group=None) -> None:

@@ -17,10 +17,11 @@ Protocol, per rank:
      mid-game mix and not 1 M boards five moves from reset;
   2. W warm-up steps of the real loop (table warm, RCCL initialised), untimed;
   3. the K-step region, timed `--repeats` times back to back on the same run (each region =
-     ceil(K / steps_per_launch) launches + the statistics all-reduce, bracketed by barrier +
-     synchronize -- the closing barrier is that all-reduce, a collective over all ranks that nobody
-     passes before every rank's steps are in; MAX over ranks): the MEDIAN region is the one
-     reported.  Every region must
+     ceil(K / steps_per_launch) launches + the statistics of the region on the host, bracketed by
+     barrier + synchronize -- with several ranks the closing barrier is the statistics reduction, one
+     collective over all ranks that nobody passes before every rank's steps are in; with one process
+     the statistics are read from the rollout's host-side mirror after the closing synchronize; MAX
+     over ranks): the MEDIAN region is the one reported.  Every region must
      finish episodes (`stats.episodes > 0`), or the reset / terminal-row path was not measured.
 Boards, aux records and the hash Q-table are resident in HBM throughout.  Rank 0 prints ONE
 JSON line.
@@ -109,6 +110,12 @@ def parse_args(argv=None):
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 = skip")
     p.add_argument("--experiment-bits", type=lambda v: int(v, 0), default=0,
                    help="unstable tuning bits OR-ed into the fused kernel's flags (ablations; not ABI)")
+    p.add_argument("--no-row-cache", action="store_true",
+                   help="A/B: launches start from a probe of the table instead of the row cache their "
+                        "predecessor left (q2048_rollout_opts.row_cache)")
+    p.add_argument("--stats-by-copy", action="store_true",
+                   help="A/B: a region's statistics come back by a device-to-host copy queued behind the "
+                        "launches (StatsAllReduce) instead of the rollout's host-side mirror")
     p.add_argument("--no-companions", action="store_true",
                    help="skip the 2^28-slot, eps = 0.01 and 5x5 companion runs (N = 1 only anyway)")
     p.add_argument("--check-shards", action="store_true",
@@ -223,7 +230,7 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
                                           exploration_rate=eps, capacity_log2=cap_log2,
                                           seed=args.seed, env_id0=shard.env_id0, device=dev,
                                           strict_td=args.strict_td, board_size=board_size,
-                                          placement=placement)
+                                          placement=placement, row_cache=not args.no_row_cache)
         synth = agent
         agent.experiment_bits = args.experiment_bits
 
@@ -253,33 +260,44 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
     reducer.start(agent.stats_i, agent.stats_f)      # untimed: RCCL builds its rings lazily
     reducer.wait()
 
-    # 3. timed regions
+    # 3. timed regions.  What a region holds besides its launches is kept small on purpose: the two HIP
+    # events exist before the clock starts; with one process the statistics come back through the
+    # rollout's own host-side mirror (written by the launch's last block: nothing is queued behind the
+    # kernel) and the closing synchronize is the only wait; with several ranks the statistics reduction
+    # -- ONE collective, on its own stream -- is the closing barrier: nobody gets past it before every
+    # rank's K steps are in.  MAX over ranks of every region's times: one collective after the last region.
+    mirrored = (not torch.distributed.is_initialized() and hasattr(agent, "mirrored_stats")
+                and not args.stats_by_copy)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(repeats)]
     regions = []
-    for _ in range(repeats):
+    for ev0, ev1 in events:
         agent.stats(reset=True)
         torch.cuda.synchronize(dev)
         pkg.dist.barrier()
         torch.cuda.synchronize(dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
         launches = run(steps)                        # exactly K steps
         ev1.record()
-        reducer.start(agent.stats_i, agent.stats_f)  # the path's only collective, on its own stream
-        si, sf = reducer.wait()
-        torch.cuda.synchronize(dev)
-        # The closing barrier of the region is the reduction itself -- a collective over all ranks: nobody
-        # gets past it before every rank's K steps are in -- followed by synchronize.  MAX over ranks below.
+        if mirrored:
+            torch.cuda.synchronize(dev)
+            si, sf = agent.mirrored_stats()
+        else:
+            reducer.start(agent.stats_i, agent.stats_f)  # the path's only collective, on its own stream
+            si, sf = reducer.wait()
+            torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
-        pkg.dist.barrier()                           # (a second, explicit one: outside the clock)
-        torch.cuda.synchronize(dev)
         st = pkg.stats_dict(si, sf)                  # all-reduced: whole-job numbers
         total = shard.total_envs * steps
         assert st["steps"] == total, (st["steps"], total)
         assert st["episodes"] > 0, "no episode finished inside a timed region: reset path unmeasured"
-        regions.append({"wall_s": pkg.dist.max_over_ranks(wall, device=dev),
-                        "kernel_ms": pkg.dist.max_over_ranks(ev0.elapsed_time(ev1), device=dev),
-                        "launches": launches, "stats": st})
+        regions.append({"wall_s": wall, "kernel_ms": ev0.elapsed_time(ev1), "launches": launches, "stats": st})
+    if mirrored:                                     # the mirror against the device vectors themselves
+        assert pkg.stats_dict(*agent.mirrored_stats()) == agent.stats(), "statistics mirror != device vectors"
+    worst = pkg.dist.max_over_ranks_many([r["wall_s"] for r in regions] + [r["kernel_ms"] for r in regions],
+                                         device=dev)
+    for k, r in enumerate(regions):
+        r["wall_s"], r["kernel_ms"] = worst[k], worst[len(regions) + k]
     table_rows = agent.table_size() if args.agent == "hash" else None
     status = agent.check_status()
     placement_report = getattr(agent, "placement", None)
@@ -392,6 +410,9 @@ def run_rank(args):
                    "alpha": args.alpha, "gamma": args.gamma, "seed": args.seed,
                    "td_write": "compare-and-swap" if args.strict_td else "store (last writer wins)",
                    "table_placement": m["placement"], "experiment_bits": args.experiment_bits,
+                   "row_cache": not args.no_row_cache,
+                   "region_statistics": "all-gather (one collective)" if world > 1 or args.stats_by_copy or args.agent != "hash"
+                                        else "host-side mirror written by the launch's last block",
                    "prep_steps": args.prep_steps, "repeats": args.repeats,
                    "timing": "median of `repeats` K-step regions after `prep_steps` of random play "
                              "and `warmup` learning steps",

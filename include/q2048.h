@@ -42,8 +42,10 @@
 extern "C" {
 #endif
 
-#define Q2048_ABI_VERSION 3 /* 3: flag bits outside the ABI are refused (Q2048_ERR_FLAGS), Q2048_ST_CAS_FALLBACK,
-                               deterministic step sorted by a hash of (state, action) */
+#define Q2048_ABI_VERSION 4 /* 3: flag bits outside the ABI are refused (Q2048_ERR_FLAGS), Q2048_ST_CAS_FALLBACK,
+                               deterministic step sorted by a hash of (state, action)
+                               4: q2048_fused_rollout_opts (row cache + statistics mirror of the fused
+                               rollout), q2048_table_grow, q2048_table_alloc verifies its zero fill */
 
 /* return codes */
 #define Q2048_OK 0
@@ -289,6 +291,47 @@ int q2048_fused_rollout_log(uint8_t *boards, q2048_aux *aux, q2048_slot *table, 
                             int64_t *stats_i, double *stats_f, uint32_t *status,
                             q2048_episode *log, int64_t log_capacity, uint64_t *log_count,
                             void *stream);
+
+/* q2048_fused_rollout with optional extras, all caller-owned, any of them NULL (opts == NULL is
+ * q2048_fused_rollout itself).  The launch boundary cuts the loop of Agent/main.py:91-101 between two
+ * iterations; the extras are what makes a cut cheap:
+ *   log, log_capacity, log_count   as q2048_fused_rollout_log.
+ *   row_cache   the row cache of the 4-call API (above: q2048_sizeof_rowcache(n) bytes per env, 16-byte
+ *               aligned, zero-filled = empty), shared with it.  A launch ENDS by leaving in record i the row
+ *               env i carries in registers -- key, the four values, slot -- and STARTS from that record when
+ *               its key is the key of the board it is given (a coalesced 32-byte read) instead of probing
+ *               the table (a scattered 128-byte request per lane: 21.5 us of every launch at 2^20 boards).
+ *               K steps in launches of S with the cache are the K-step launch: a row is carried across the
+ *               cut exactly as across a step.  Any calling pattern is correct (a record is used only on a
+ *               key match); like a row carried in registers, a record does not see what OTHER envs wrote to
+ *               its row since.  Q2048_FLAG_PLAY_ONLY launches neither read nor write it.
+ *   stats_mirror, mirror_ticket   stats_mirror: (Q2048_NSTAT_I + Q2048_NSTAT_F + 1) 8-byte words the HOST
+ *               can read while the device writes them -- pinned host memory mapped into the device's
+ *               address space (hipHostMalloc; any 8-byte aligned pointer the device can store to works).
+ *               The last block of the launch to finish copies stats_i then stats_f (both required then), as
+ *               they stand after the whole launch's additions, into words 0..35 and writes the number of
+ *               mirrored launches so far into word Q2048_MIRROR_SEQ: a caller that waits for the launch
+ *               anyway (hipStreamSynchronize) reads its statistics from host memory with no copy queued
+ *               behind the kernel.  mirror_ticket: device uint32[2], zero before its first use, private to
+ *               one stream of launches (two launches that share it must not overlap).
+ * `size` = sizeof(q2048_rollout_opts): a caller built against another layout is refused (Q2048_ERR_SIZE). */
+#define Q2048_MIRROR_SEQ 36 /* = Q2048_NSTAT_I + Q2048_NSTAT_F */
+#define Q2048_MIRROR_WORDS 37
+typedef struct q2048_rollout_opts {
+  uint32_t size;
+  uint32_t reserved;
+  q2048_episode *log;
+  int64_t log_capacity;
+  uint64_t *log_count;
+  void *row_cache;
+  void *stats_mirror;
+  uint32_t *mirror_ticket;
+} q2048_rollout_opts;
+int q2048_fused_rollout_opts(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2,
+                             int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
+                             uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
+                             int64_t *stats_i, double *stats_f, uint32_t *status,
+                             const q2048_rollout_opts *opts, void *stream);
 
 /* Deterministic mode: reproducible shared-table training at any B (the default rollout is
  * lock-free and depends on scheduling wherever lanes share a state).  Per step:

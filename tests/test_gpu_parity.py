@@ -594,6 +594,96 @@ def test_fused_equals_unfused_and_split_launches(pkg, O):
 
 
 @pytest.mark.parametrize("n", [4, 5])
+def test_fused_rollout_row_cache_and_statistics_mirror(pkg, O, n):
+    """q2048_fused_rollout_opts: (a) K steps cut into launches of 1, 7 and 20 steps WITH the row cache
+    (a launch starts from the record its predecessor left, not from a probe) equal the single K-step
+    launch and the cut launches WITHOUT the cache bit for bit -- boards, aux, tables, statistics;
+    (b) the cache is the 4-call API's: fused launches and choose / step / update / reset iterations
+    interleaved on one agent equal the same interleaving without a cache; (c) the statistics mirror a
+    launch's last block writes to pinned host memory equals the device vectors after every launch, and a
+    reader that did not wait for the right launch is refused; (d) argument errors of the opts struct."""
+    B, steps, seed, id0, eps = 777, 140, 21, 4242, 0.25      # 777: a ragged last block
+
+    def mk(cache):
+        e = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+        a = pkg.BatchedQLearningAgent(100, exploration_rate=eps, discount_factor=0.95, capacity_log2=18,
+                                      seed=seed, env_id0=id0, device=DEV, independent=True, board_size=n,
+                                      row_cache=cache)
+        return e, a
+
+    def cut(e, a, pattern):
+        left, k = steps, 0
+        while left > 0:
+            s_ = min(pattern[k % len(pattern)], left)
+            a.fused_rollout(e, s_)
+            torch.cuda.synchronize()
+            assert pkg.stats_dict(*a.mirrored_stats()) == a.stats()                 # (c)
+            left -= s_; k += 1
+
+    def table(a):
+        k, q = a.export_rows()
+        o = np.lexsort(k.reshape(len(q), -1).T[::-1])
+        return k[o], q[o]
+
+    e0, a0 = mk(True); a0.fused_rollout(e0, steps)
+    ref_k, ref_q = table(a0)
+    for cache in (True, False):
+        for pattern in ((1,), (7,), (20, 3, 1)):
+            e, a = mk(cache); cut(e, a, pattern)
+            assert torch.equal(e.boards, e0.boards) and torch.equal(e.aux, e0.aux), (cache, pattern)
+            k, q = table(a)
+            assert np.array_equal(k, ref_k) and np.array_equal(q, ref_q), (cache, pattern)
+            s0, s1 = a0.stats(), a.stats()
+            for key in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "explored", "drops"):
+                assert s0[key] == s1[key], (cache, pattern, key)
+            if cache:      # a record holds the key of the board the env is on, unless its row does not exist yet
+                rec = a._row_cache.cpu().numpy()
+                assert (rec.view(np.uint64)[:, 0] != 0).mean() > 0.95
+    # (b) fused launches and 4-call iterations interleaved, with and without the shared cache
+    outs = []
+    for cache in (True, False):
+        e, a = mk(cache)
+        s = e.boards
+        for rnd in range(6):
+            a.fused_rollout(e, 9)
+            s = e.boards
+            for _ in range(5):
+                act = a.choose_action(s)
+                s2, r, d, _info = e.step(act)
+                a.update_q_value(s, act, r, s2, d)
+                s = e.reset(d)
+        outs.append((e.boards.clone(), e.aux.clone(), table(a), a.stats()["inserts"], a.table_size()))
+        assert a.check_status() == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2][0], outs[1][2][0]) and np.array_equal(outs[0][2][1], outs[1][2][1])
+    assert outs[0][3] == outs[1][3] == outs[0][4]
+    # (c) a stale mirror is refused
+    e, a = mk(True); a.fused_rollout(e, 3); torch.cuda.synchronize(); a.mirrored_stats()
+    a._mirror_launches += 1
+    with pytest.raises(RuntimeError):
+        a.mirrored_stats()
+    # (d) the opts struct: another layout, a mirror without its ticket or without both vectors, alignment
+    L, Nn = pkg._native.lib(), pkg._native
+    e, a = mk(True)
+
+    def call(opts, stats_f=True):
+        return L.q2048_fused_rollout_opts(
+            e.boards.data_ptr(), e.aux.data_ptr(), a.table.data_ptr(), a.capacity_log2, B, n, 1, 0.5, 0.1, 0.9,
+            seed, id0, 0, Nn.FLAG_INDEPENDENT, a.stats_i.data_ptr(), a.stats_f.data_ptr() if stats_f else None,
+            a.status.data_ptr(), C.byref(opts) if opts is not None else None, None)
+
+    bad = Nn.RolloutOpts(); bad.size = 8
+    assert call(bad) == -2
+    assert call(Nn.RolloutOpts(stats_mirror=a._mirror.data_ptr())) == -1
+    assert call(Nn.RolloutOpts(stats_mirror=a._mirror.data_ptr(), mirror_ticket=a._mirror_ticket.data_ptr()),
+                stats_f=False) == -1
+    assert call(Nn.RolloutOpts(row_cache=a._cache(B).data_ptr() + 8)) == -3
+    assert call(Nn.RolloutOpts(stats_mirror=a._mirror.data_ptr() + 4, mirror_ticket=a._mirror_ticket.data_ptr())) == -3
+    assert call(None) == 0 and call(Nn.RolloutOpts()) == 0
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n", [4, 5])
 def test_four_call_loop_without_copies_and_row_cache(pkg, O, n):
     """The batched loop of Agent/main.py:92-100 written WITHOUT a board copy (step ping-pongs two
     buffers: the tensor that was env.boards stays the pre-step state) and with the row cache
