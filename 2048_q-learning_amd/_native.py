@@ -152,6 +152,9 @@ _SIGNATURES = {
                                            C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.POINTER(RolloutOpts), C.c_void_p]),
     "q2048_table_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "q2048_table_reserve": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "q2048_table_grow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_int64), C.c_void_p]),
     "q2048_table_free": (C.c_int, [C.c_void_p]),
     "q2048_table_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_void_p]),
     "q2048_table_count": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -110,23 +110,31 @@ def _probe_us(table: torch.Tensor, capacity_log2: int, device: torch.device) -> 
 
 
 class _ChunkedTable:
-    """Owner of one q2048_table_alloc allocation (a table mapped from 2 MiB physical chunks),
-    handed to torch through __cuda_array_interface__: the tensor keeps this object alive, and the
-    memory goes back to the device when the last reference is dropped."""
+    """Owner of one q2048_table_reserve allocation (a table mapped from 2 MiB physical chunks, in an
+    address range with room for every capacity up to `max_capacity_log2`), handed to torch through
+    __cuda_array_interface__: the tensor keeps this object alive, and the memory goes back to the
+    device when the last reference is dropped."""
 
-    def __init__(self, capacity_log2: int, device: torch.device, chunk_bytes: int = 0):
-        ptr = C.c_void_p()
-        with torch.cuda.device(device):
-            N.check(N.lib().q2048_table_alloc(capacity_log2, chunk_bytes, C.byref(ptr)), "q2048_table_alloc")
-        self.ptr = int(ptr.value)
-        self.__cuda_array_interface__ = {"shape": (1 << capacity_log2, N.SIZEOF_SLOT), "typestr": "|u1",
+    def __init__(self, capacity_log2: int, device: torch.device, chunk_bytes: int = 0,
+                 max_capacity_log2: int | None = None, _adopt: int | None = None):
+        self.capacity_log2 = int(capacity_log2)
+        self.max_capacity_log2 = int(max_capacity_log2 or capacity_log2)
+        self.device = device
+        if _adopt is None:
+            ptr = C.c_void_p()
+            with torch.cuda.device(device):
+                N.check(N.lib().q2048_table_reserve(self.capacity_log2, self.max_capacity_log2, chunk_bytes,
+                                                    C.byref(ptr)), "q2048_table_reserve")
+            _adopt = int(ptr.value)
+        self.ptr = _adopt
+        self.__cuda_array_interface__ = {"shape": (1 << self.capacity_log2, N.SIZEOF_SLOT), "typestr": "|u1",
                                          "data": (self.ptr, False), "version": 2, "strides": None}
         self._finalizer = weakref.finalize(self, _ChunkedTable._free, self.ptr)
 
     @staticmethod
     def _free(ptr: int) -> None:
         try:
-            N.lib().q2048_table_free(ptr)
+            N.lib().q2048_table_free(ptr)       # synchronises the table's own device, whatever the current one is
         except Exception:                       # interpreter shutdown: the process's memory goes anyway
             pass
 
@@ -136,6 +144,16 @@ class _ChunkedTable:
             raise RuntimeError("torch did not adopt the chunked table in place")
         return t
 
+    def grow(self, new_capacity_log2: int, key_words: int, stream) -> "tuple[_ChunkedTable, int]":
+        """q2048_table_grow: the table of the next capacity, every row moved over, this one released
+        (its tensor must not be used again).  Returns (owner of the bigger table, rows moved)."""
+        ptr, moved = C.c_void_p(), C.c_int64(0)
+        N.check(N.lib().q2048_table_grow(self.ptr, self.capacity_log2, int(new_capacity_log2), key_words,
+                                         C.byref(ptr), C.byref(moved), stream), "q2048_table_grow")
+        self._finalizer.detach()                # the library released this table's chunks itself
+        return _ChunkedTable(new_capacity_log2, self.device, max_capacity_log2=self.max_capacity_log2,
+                             _adopt=int(ptr.value)), int(moved.value)
+
 
 def _ranks_on_this_device() -> int:
     """How many ranks of this job run on each GPU (1 on a real multi-GPU node)."""
@@ -143,7 +161,7 @@ def _ranks_on_this_device() -> int:
     return max(1, -(-world // max(torch.cuda.device_count(), 1)))
 
 
-def place_table(capacity_log2: int, device: torch.device, placement="auto"):
+def place_table(capacity_log2: int, device: torch.device, placement="auto", max_capacity_log2: int | None = None):
     """Allocate the zeroed table where scattered writes run fast.
 
     How a multi-GiB table's memory was obtained moves the scattered store / atomic rate of the
@@ -159,13 +177,15 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto"):
       "plain"   torch.zeros (caching allocator -> hipMalloc): whatever the device yields
       n (int)   allocate up to n plain candidates at once, time q2048_table_probe on each (~2 ms,
                 contents untouched), keep the fastest, release the others
+    `max_capacity_log2` ("chunks" only): the table's address range has room for every capacity up to
+    that one (`BatchedQLearningAgent.grow_table`).
     Returns (table, report); report["probe_us"] lists the probe's time on every candidate tried."""
     shape = (1 << capacity_log2, N.SIZEOF_SLOT)
     nbytes = N.SIZEOF_SLOT << capacity_log2
     if placement == "auto":
         if (1 << 30) <= nbytes <= (64 << 30):
             try:
-                return place_table(capacity_log2, device, "chunks")
+                return place_table(capacity_log2, device, "chunks", max_capacity_log2)
             except (N.NativeError, RuntimeError) as exc:      # no virtual-memory API on this stack, or no room:
                 table = torch.zeros(shape, dtype=torch.uint8, device=device)   # the slower kind of table
                 return table, {"mode": "plain", "chunks_failed": str(exc)}
@@ -182,14 +202,16 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto"):
         tables, times = [], []
         for _ in range(tries):
             try:
-                t = _ChunkedTable(capacity_log2, device).tensor(device)
+                owner = _ChunkedTable(capacity_log2, device, max_capacity_log2=max_capacity_log2)
+                t = owner.tensor(device)
+                t._q2048_owner = owner                  # how grow_table finds the allocation again
             except N.NativeError:
                 if not tables:
                     raise
                 break                                   # the memory went elsewhere meanwhile: keep what there is
             tables.append(t)
             times.append(_probe_us(t, capacity_log2, device))
-            del t
+            del t, owner
         chosen = int(np.argmin(times))
         table = tables[chosen]
         del tables
@@ -235,9 +257,17 @@ class BatchedQLearningAgent:
     """QLearningAgent over a batch.  Constructor arguments as Agent/main.py:15; extra keyword
     arguments size and place the device table.
 
-    capacity_log2   the table has 2**capacity_log2 slots of 32 B, fixed at construction.  When an
+    capacity_log2   an int: the table has 2**capacity_log2 slots of 32 B, fixed at construction; when an
                     update finds no free slot within the probe limit it is dropped and counted
                     (stats['drops'], status TABLE_FULL) -- never an exception.
+                    "auto": a table that GROWS, like the reference's defaultdict (Agent/main.py:16): it
+                    starts at 2**initial_capacity_log2 slots (2^28 = 8 GiB) and, between launches, doubles
+                    whenever the rows it holds pass `load_limit` (0.5) of its capacity
+                    (q2048_table_grow: the next capacity mapped further along one reserved address range,
+                    every row moved over by one streaming kernel, the smaller table released), up to the
+                    largest capacity the device has room for next to its predecessor (2^32 slots =
+                    128 GiB on an MI355X); `growths` lists what happened.  No update is dropped in any
+                    run that fits the device.
     independent     every env owns private rows (keys salted with its global id): B independent
                     learners in one table, exactly B reference agents side by side.
     placement       how the table is allocated (`place_table`): "auto", "chunks", "plain" or a count
@@ -253,13 +283,27 @@ class BatchedQLearningAgent:
     def __init__(self, total_epochs, action_space=4, learning_rate=0.1, discount_factor=0.9,
                  exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 24,
                  device="cuda", seed: int = 0, env_id0: int = 0, independent: bool = False,
-                 strict_td: bool = False, board_size: int = 4, placement="auto", row_cache: bool = True):
+                 strict_td: bool = False, board_size: int = 4, placement="auto", row_cache: bool = True,
+                 initial_capacity_log2: int = 28, max_capacity_log2: int | None = None, load_limit: float = 0.5):
         self.device = _require_gpu(device)
         if action_space != 4:
             raise ValueError("the 2048 action space has 4 actions")
         if board_size not in (4, 5):
             raise NotImplementedError("board_size must be 4 (the reference) or 5")
         self.board_size, self.cells = int(board_size), int(board_size) ** 2
+        self.growable = capacity_log2 == "auto"
+        self.load_limit, self.growths = float(load_limit), []
+        if self.growable:
+            if not 0.05 <= self.load_limit <= 0.9:
+                raise ValueError("load_limit must be in [0.05, 0.9]")
+            capacity_log2 = int(initial_capacity_log2)
+            # the largest table that fits next to its predecessor (1.5 x its size while rows move over)
+            free, _ = torch.cuda.mem_get_info(self.device)
+            fit = int(np.floor(np.log2(max(0.9 * free / _ranks_on_this_device() / (1.5 * N.SIZEOF_SLOT), 16.0))))
+            self.max_capacity_log2 = max(capacity_log2, min(int(max_capacity_log2 or 34), fit, 40))
+            placement = "chunks"                      # growth is a property of the chunk allocator
+        else:
+            self.max_capacity_log2 = int(capacity_log2)
         if not 4 <= capacity_log2 <= 40:
             raise ValueError("capacity_log2 must be in [4, 40]")
         self.action_space = action_space                                       # :21
@@ -272,7 +316,13 @@ class BatchedQLearningAgent:
         self.flags = (N.FLAG_INDEPENDENT if independent else 0) | (N.FLAG_TD_CAS if strict_td else 0)
         self.experiment_bits = 0  # unstable tuning bits OR-ed into fused_rollout's flags
         self.ctr = 0  # choose_action calls so far = counter word of the step draws
-        self.table, self.placement = place_table(self.capacity_log2, self.device, placement)
+        self.table, self.placement = place_table(self.capacity_log2, self.device, placement,
+                                                 self.max_capacity_log2 if self.growable else None)
+        # row bookkeeping (growth, `verify_table`): rows known to be in the table at the last count, the
+        # upper bound on rows created since (two per env-step: a state's own row and its successor's), the
+        # cumulative insert counter (statistics resets fold into it) and its value at the last count
+        self._rows_known, self._rows_maybe = 0, 0
+        self._inserts_folded, self._inserts_at_count = 0, 0
         self.stats_i, self.stats_f = new_stats_vectors(self.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.q_table = _QTableView(self)
@@ -335,6 +385,7 @@ class BatchedQLearningAgent:
         actions = self._vec(actions, torch.uint8, B, "actions")
         reward = self._vec(reward, torch.float32, B, "reward")
         done = self._vec(done, torch.uint8, B, "done")
+        self._room_for(B)
         N.check(N.lib().q2048_q_update_cached(
             _ptr(self.table), self.capacity_log2, _ptr(boards), _ptr(actions), _ptr(reward),
             _ptr(next_boards), _ptr(done), B, self.board_size, float(self.lr), float(self.gamma), self.env_id0,
@@ -376,6 +427,8 @@ class BatchedQLearningAgent:
         if env.ctr != self.ctr:
             raise ValueError(f"env.ctr={env.ctr} and agent.ctr={self.ctr} are out of step")
         log = episode_log
+        if learn and not play_only:
+            self._room_for(env.num_envs * int(steps))
         # the row every env carries goes from launch to launch (and to choose_action / update_q_value)
         # through the row cache; a learner-less launch touches neither the table nor the cache
         cache = None if play_only else self._cache(env.num_envs)
@@ -426,6 +479,7 @@ class BatchedQLearningAgent:
         if ws is None or ws.numel() < need + 256:
             ws = self._det_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = (ws.data_ptr() + 255) & ~255                       # the workspace is 256-byte aligned
+        self._room_for(B * int(steps))
         self.invalidate_row_cache()
         N.check(L.q2048_det_rollout(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, B, self.board_size,
@@ -435,12 +489,91 @@ class BatchedQLearningAgent:
         env.ctr += int(steps)
         self.ctr += int(steps)
 
+    # -- a table that grows (capacity_log2="auto") ------------------------------------------------
+    def _room_for(self, env_steps: int) -> None:
+        """Called before anything that may create rows: `env_steps` env-steps are about to run, each
+        of which creates at most two rows (a state's own and its successor's, Agent/main.py:41-43).
+        Cheap while the bound says the table cannot pass its load limit; otherwise the rows are
+        counted (one streaming pass, synchronising) and the table doubles until the expected rows of
+        the call -- one per env-step -- fit under the limit."""
+        self._rows_maybe += 2 * int(env_steps)
+        if not self.growable:
+            return
+        limit = self.load_limit * (1 << self.capacity_log2)
+        if self._rows_known + self._rows_maybe <= limit:
+            return
+        self._count_rows()
+        self._rows_maybe = 2 * int(env_steps)
+        while (self._rows_known + int(env_steps) > self.load_limit * (1 << self.capacity_log2)
+               and self.capacity_log2 < self.max_capacity_log2):
+            self.grow_table()
+
+    def _cumulative_inserts(self) -> int:
+        return self._inserts_folded + int(self.stats_i[N.ST_INSERTS].item())
+
+    def _count_rows(self) -> int:
+        """Occupied slots, counted on the device (synchronising); the new base of the row bookkeeping."""
+        self._rows_known = self.table_size()
+        self._inserts_at_count = self._cumulative_inserts()
+        self._rows_maybe = 0
+        return self._rows_known
+
+    def grow_table(self, new_capacity_log2: int | None = None) -> int:
+        """Doubles the table (or takes it to 2**new_capacity_log2 slots): q2048_table_grow maps the new
+        capacity further along the table's reserved address range, moves every row over with one streaming
+        kernel and releases the smaller table -- after checking that the new table holds exactly the rows
+        the old one held.  Values are untouched, slots change: the row cache is emptied.  Only tables
+        made with capacity_log2="auto" can grow.  Returns the rows moved."""
+        owner = getattr(self.table, "_q2048_owner", None)
+        if not self.growable or owner is None:
+            raise RuntimeError('only a table made with capacity_log2="auto" can grow')
+        new = self.capacity_log2 + 1 if new_capacity_log2 is None else int(new_capacity_log2)
+        if not self.capacity_log2 < new <= self.max_capacity_log2:
+            raise ValueError(f"cannot grow from 2^{self.capacity_log2} to 2^{new} slots "
+                             f"(this table's range ends at 2^{self.max_capacity_log2})")
+        t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0[0].record()
+        with torch.cuda.device(self.device):     # (raises with the old table intact and still self.table)
+            bigger, moved = owner.grow(new, 1 if self.board_size == 4 else 2, _stream(self.device))
+        self.table = bigger.tensor(self.device)  # the old tensor's memory is gone: nothing else may hold it
+        self.table._q2048_owner = bigger
+        t0[1].record()
+        t0[1].synchronize()
+        self.growths.append({"from_log2": self.capacity_log2, "to_log2": new, "rows": moved,
+                             "ms": round(t0[0].elapsed_time(t0[1]), 3), "at_step": self.ctr})
+        self.capacity_log2 = new
+        self.invalidate_row_cache()
+        self._rows_known, self._rows_maybe = moved, 0
+        self._inserts_at_count = self._cumulative_inserts()
+        return moved
+
+    def verify_table(self) -> dict:
+        """Run-time check that no row was lost or duplicated: the slots occupied now == the rows counted
+        at the last count / import / growth + the rows the kernels say they created since
+        (Q2048_ST_INSERTS).  One streaming pass over the table (1.3 ms per 8 GiB), synchronising.
+        Raises RuntimeError on a mismatch; returns the numbers."""
+        created = self._cumulative_inserts() - self._inserts_at_count
+        expect = self._rows_known + created
+        rows = self.table_size()
+        timeouts = N.claim_timeouts()
+        if rows != expect or timeouts:
+            raise RuntimeError(f"Q-table self-check failed: {rows} occupied slots, expected {expect} "
+                               f"({self._rows_known} counted earlier + {created} created since); "
+                               f"{timeouts} 5x5 claim time-outs")
+        self._rows_known, self._rows_maybe = rows, 0
+        self._inserts_at_count = self._cumulative_inserts()
+        return {"rows": rows, "capacity_log2": self.capacity_log2, "load": rows / float(1 << self.capacity_log2)}
+
     # -- statistics / table access ---------------------------------------------------------
-    def stats(self, reset: bool = False) -> dict:
-        """Synchronising host copy of the device statistics."""
+    def stats(self, reset: bool = False, verify: bool = False) -> dict:
+        """Synchronising host copy of the device statistics.  `verify`: also `verify_table()` -- the
+        occupied slots must equal the rows counted earlier + the rows created since."""
         si = self.stats_i.cpu().numpy()
         sf = self.stats_f.cpu().numpy()
+        if verify:
+            self.verify_table()
         if reset:
+            self._inserts_folded += int(si[N.ST_INSERTS])
             self.stats_i.zero_()
             self.stats_f.zero_()
         return stats_dict(si, sf)
@@ -515,6 +648,7 @@ class BatchedQLearningAgent:
         vars(self.schedule).update(sd["schedule"])
         self.stats_i.copy_(sd["stats_i"])
         self.stats_f.copy_(sd["stats_f"])
+        self._inserts_folded = 0
         self.invalidate_row_cache()
         self.table.zero_()
         if "table" in sd:
@@ -523,6 +657,7 @@ class BatchedQLearningAgent:
             self.table.copy_(sd["table"])
         else:
             self.import_rows(sd["keys"], sd["q"])
+        self._count_rows()
 
     def import_rows(self, keys: np.ndarray, q: np.ndarray) -> None:
         """Inserts (key, q[4]) rows exported by `export_rows` (any capacity that holds them)."""
@@ -531,6 +666,8 @@ class BatchedQLearningAgent:
         if rows == 0:
             return
         self.invalidate_row_cache()
+        while self.growable and rows * 2 > (1 << self.capacity_log2) and self.capacity_log2 < self.max_capacity_log2:
+            self.grow_table()
         if rows * 2 > (1 << self.capacity_log2):
             raise ValueError("table too small for the checkpoint (load factor would exceed 0.5)")
         tk = torch.from_numpy(keys.view(np.int64)).to(self.device)
@@ -541,6 +678,7 @@ class BatchedQLearningAgent:
                                            _stream(self.device)), "table_import")
         if int(status.item()) & N.STATUS_TABLE_FULL:
             raise RuntimeError("table_import dropped rows (probe limit)")
+        self._count_rows()
 
     # -- argument plumbing -----------------------------------------------------------------
     def _boards(self, b) -> torch.Tensor:

@@ -38,7 +38,11 @@ namespace {
 using namespace q2048;
 
 constexpr int kBlock = 256;
-constexpr int kMaxProbe = 256;   // probe limit: beyond it a lookup reads "absent", an update drops
+// Probe limit: beyond it a lookup reads "absent" and an update drops (counted; status TABLE_FULL).  It is
+// what makes a probe of a FULL table end, not a load policy: at load 0.93 the longest cluster of a 2^22-slot
+// table is already thousands of slots (ln n / (a - 1 - ln a)), and round 3's limit of 256 made "full" mean
+// "load ~0.85" (a racing import at load 0.93 dropped rows).  2^14 slots, or the whole table if smaller.
+constexpr uint32_t kMaxProbe = 1u << 14;
 constexpr int kMaxCas = 16;      // TD compare-and-swap attempts before the update is simply stored
 
 static_assert(sizeof(q2048_aux) == 16 && sizeof(q2048_slot) == 32, "ABI layout");
@@ -203,6 +207,10 @@ __device__ __forceinline__ uint32_t seq_pos(const Seq& s, u64 slot) { // inverse
   return ((uint32_t)(((slot >> 2) - s.line0) & s.lmask) << 2) | (((uint32_t)slot - s.off) & 3u);
 }
 
+__device__ __forceinline__ uint32_t probe_limit(u64 mask) {
+  return mask >= (u64)kMaxProbe ? kMaxProbe : (uint32_t)mask + 1u;
+}
+
 // ---------------------------------------------------------------------------------------------
 // hash table.  Readers use agent-scope relaxed loads (they bypass the per-CU L1, which other
 // CUs' atomics never refresh); rows are claimed with a device-scope compare-and-swap on the key
@@ -288,7 +296,7 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
   const Seq sq = seq_of(key_hash(key), mask);
   created = false;
   row = Row{0.f, 0.f, 0.f, 0.f};
-  for (uint32_t p = 0; p < (uint32_t)kMaxProbe; ++p) {
+  for (uint32_t p = 0, lim = probe_limit(mask); p < lim; ++p) {
     const u64 i = seq_slot(sq, p);
     const u32x4 v = ld16_agent(&table[i]);
     const u64 k = (u64)v.x | ((u64)v.y << 32);
@@ -310,7 +318,7 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
   const Seq sq = seq_of(key_hash(key), mask);
   created = false;
   row = Row{0.f, 0.f, 0.f, 0.f};
-  for (uint32_t p = 0; p < (uint32_t)kMaxProbe; ++p) {
+  for (uint32_t p = 0, lim = probe_limit(mask); p < lim; ++p) {
     const u64 i = seq_slot(sq, p);
     const u32x4 a = ld16_agent(&table[i]);
     const u64 k = (u64)a.x | ((u64)a.y << 32);
@@ -338,7 +346,7 @@ __device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, con
   u64 i = start & mask;
   inserted = false;
   u64 k = 0ull;                                      // the hinted slot: straight to the compare-and-swap
-  for (uint32_t p = seq_pos(sq, i); p < (uint32_t)kMaxProbe; i = seq_slot(sq, ++p), k = ld_u64(&table[i].key)) {
+  for (uint32_t p = seq_pos(sq, i), lim = probe_limit(mask); p < lim; i = seq_slot(sq, ++p), k = ld_u64(&table[i].key)) {
     if (k == 0ull) k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key.k0);
     if ((k == 0ull || k == key.k0) && confirm(&table[i], key, k == 0ull, inserted)) return (int64_t)i;
   }
@@ -500,22 +508,38 @@ __global__ __launch_bounds__(64) void k_stats_fold(const StatStripe* stripes, in
 // statistics vectors, as they stand after every block's flush, into `mirror` -- a buffer the HOST can
 // read (pinned host memory mapped into the device's address space) -- so a caller that waits for the
 // launch anyway needs no device-to-host copy behind it (a 288-byte copy queued on the stream cost the
-// bench's 1 ms region 15-18 us, profiles/r03_region_overhead.txt).  "Last" is decided by a ticket:
-// every block, after its own statistics atomics have been acknowledged (agent-scope release fence),
-// takes a number; the block that draws gridDim.x - 1 knows all the others are in, reads the vectors
-// at the memory side (agent-scope loads: the adds were device-scope atomics, no L2 holds anything
-// newer) and writes them out with system-scope stores, followed by the number of mirrored launches so
-// far (ticket[1], mirror[Q2048_MIRROR_SEQ]: how the host tells a fresh mirror from the last one), and
-// resets the ticket for the next launch.  ticket = device uint32[2], zero before its first use.
-__device__ __forceinline__ void stats_mirror(const int64_t* gi, const double* gf, u64* mirror, uint32_t* ticket) {
-  if (mirror == nullptr) return;                          // (uniform over the grid)
-  __shared__ uint32_t my_ticket;
-  __threadfence();                                        // this thread's statistics atomics are performed
+// bench's 1 ms region 15-18 us, profiles/r03_region_overhead.txt).  "Last" is decided by a ticket: every
+// block, once its own statistics atomics have been PERFORMED, takes a number; the block that draws
+// gridDim.x - 1 knows all the others are in, reads the vectors where the atomics were performed
+// (agent-scope loads) and writes them out with system-scope stores, followed by the number of mirrored
+// launches so far (ticket[1], mirror[Q2048_MIRROR_SEQ]: how the host tells a fresh mirror from the last
+// one), and resets the ticket for the next launch.  ticket = device uint32[2], zero before its first use.
+//
+// No fences.  An agent-scope release fence on this chip writes back every dirty line of the XCD's L2, and
+// this kernel's L2s are full of freshly written Q values: `__threadfence()` per block made a 20-step launch
+// 2.3 ms instead of 0.95 (gpurun_out/r04a).  Order comes from the atomics themselves: the flush uses the
+// RETURNING form and waits for the answers -- a device-scope atomic has been performed at the memory side
+// when its old value is back -- before the block's ticket atomic is issued, to the same coherence point.
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void stats_flush_acked(BlockStats& s, int64_t* gi, double* gf) {
   __syncthreads();
-  if (threadIdx.x == 0) my_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < Q2048_NSTAT_I && s.i[threadIdx.x] != 0ull) {
+    const u64 old = atomicAdd(reinterpret_cast<u64*>(gi) + threadIdx.x, s.i[threadIdx.x]);
+    asm volatile("" :: "v"(old));                           // the returning form, and its answer waited for
+  }
+  if (threadIdx.x < Q2048_NSTAT_F && s.f[threadIdx.x] != 0.0) {
+    const double old = atomicAdd(gf + threadIdx.x, s.f[threadIdx.x]);
+    asm volatile("" :: "v"(old));
+  }
+  wait_vm();
+}
+__device__ __forceinline__ void stats_mirror(const int64_t* gi, const double* gf, u64* mirror, uint32_t* ticket) {
+  __shared__ uint32_t my_ticket;
+  __syncthreads();                                        // every thread's statistics atomics have answered
+  if (threadIdx.x == 0)
+    my_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (my_ticket != gridDim.x - 1u) return;
-  __threadfence();
   const int t = (int)threadIdx.x;
   if (t < Q2048_NSTAT_I + Q2048_NSTAT_F) {
     const u64* src = t < Q2048_NSTAT_I ? reinterpret_cast<const u64*>(gi) + t
@@ -523,13 +547,13 @@ __device__ __forceinline__ void stats_mirror(const int64_t* gi, const double* gf
     const u64 v = __hip_atomic_load(const_cast<u64*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(mirror + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __threadfence_system();
+  wait_vm();                                              // the values are out before the launch number
   __syncthreads();
   if (t == 0) {
-    const uint32_t launches = ticket[1] + 1u;             // only ever touched here, by one thread per launch
-    ticket[1] = launches;
-    __hip_atomic_store(mirror + Q2048_MIRROR_SEQ, (u64)launches, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t launches = __hip_atomic_load(ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __hip_atomic_store(ticket + 1, launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mirror + Q2048_MIRROR_SEQ, (u64)launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 __device__ __forceinline__ void episode_stats(BlockStats& s, const Aux& a, uint32_t max_l2) {
@@ -1094,8 +1118,12 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     }
   }
   store_board(boards, i, B, b, st);
-  stats_flush(bs, stats_i, stats_f);
-  stats_mirror(stats_i, stats_f, mirror, ticket);
+  if (mirror == nullptr) {                                // (uniform over the grid)
+    stats_flush(bs, stats_i, stats_f);
+  } else {
+    stats_flush_acked(bs, stats_i, stats_f);
+    stats_mirror(stats_i, stats_f, mirror, ticket);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1746,6 +1774,48 @@ __global__ __launch_bounds__(kBlock) void k_table_import(q2048_slot* table, u64 
   table[slot].q[0] = v.x; table[slot].q[1] = v.y; table[slot].q[2] = v.z; table[slot].q[3] = v.w;
 }
 
+// Growth (q2048_table_grow): every occupied row of `old_t` is inserted into `new_t` (zero-filled, larger)
+// in ONE streaming pass -- consecutive lanes read consecutive slots (32 B each, non-temporal), an
+// occupied one claims its slot in the new table with the find-or-create of the rollout (the first
+// access is the claiming compare-and-swap at the key's new home) and writes its four values.  Keys of
+// one table are distinct, so no two lanes ever insert the same key; counters[0] += rows moved,
+// counters[1] += rows that found no slot or found their key already there (expected: 0; the host
+// refuses the new table otherwise).
+template <int WORDS>
+__global__ __launch_bounds__(kBlock) void k_table_rehash(const q2048_slot* old_t, u64 old_cap, q2048_slot* new_t,
+                                                         u64 new_mask, u64* counters) {
+  const u32x4* t16 = reinterpret_cast<const u32x4*>(old_t);
+  u64 moved = 0ull, failed = 0ull;
+  for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < old_cap; i += (u64)gridDim.x * kBlock) {
+    const u32x4 a = __builtin_nontemporal_load(&t16[2ull * i]);          // {key, q0, q1}
+    const u64 k = (u64)a.x | ((u64)a.y << 32);
+    if (k == 0ull) continue;
+    const u32x4 w = __builtin_nontemporal_load(&t16[2ull * i + 1ull]);   // {q2, q3, second key word}
+    typename Geo<WORDS == 1 ? 4 : 5>::Key key;
+    key.k0 = k;
+    if constexpr (WORDS == 2) key.k1 = (u64)w.z | ((u64)w.w << 32);
+    bool inserted;
+    const int64_t slot = probe_insert(new_t, new_mask, key, key_home(key, new_mask), inserted);
+    if (slot < 0 || !inserted) { ++failed; continue; }
+    uint2* q = reinterpret_cast<uint2*>(new_t[slot].q);                  // 8-byte aligned (offset 8 of a 32-B slot)
+    q[0] = make_uint2(a.z, a.w);
+    q[1] = make_uint2(w.x, w.y);
+    ++moved;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { moved += __shfl_xor(moved, d); failed += __shfl_xor(failed, d); }
+  __shared__ u64 wm[kBlock / 64], wf[kBlock / 64];
+  if ((threadIdx.x & 63u) == 0u) { wm[threadIdx.x >> 6] = moved; wf[threadIdx.x >> 6] = failed; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 m = 0ull, f = 0ull;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { m += wm[w]; f += wf[w]; }
+    if (m) atomicAdd(&counters[0], m);
+    if (f) atomicAdd(&counters[1], f);
+  }
+}
+
 // Placement probe: `steps` scattered device-scope atomic ORs of 0 per lane into key words chosen
 // like the rollout chooses rows -- the table's write-side request pattern with no effect on its
 // contents (x | 0 == x).  The host times it: where in device memory a table lies moves the
@@ -1879,6 +1949,7 @@ const char* q2048_strerror(int code) {
     case Q2048_ERR_RANGE: return "scalar out of range (eps in [0,1], lr and gamma finite)";
     case Q2048_ERR_FLAGS: return "flag bits this entry point does not take";
     case Q2048_ERR_ALLOC: return "device memory could not be reserved, created or mapped";
+    case Q2048_ERR_VERIFY: return "a table failed its self-check (a fresh table not all zeros, or rows lost while growing)";
     default: return "unknown error";
   }
 }
@@ -2336,10 +2407,29 @@ int q2048_table_probe(q2048_slot* table, int cap_log2, int64_t lanes, int steps,
 
 // Table allocation from small physical chunks (HIP virtual-memory API).  The only entry points that
 // allocate; everything else works on caller-owned memory, wherever it came from.
+//
+// A FAMILY is one reserved address range with room for a table of every capacity from cap0 to max, one
+// after the other (offset of capacity 2^k = the sizes of the smaller ones before it: < 2 x the largest
+// in all).  q2048_table_reserve maps the first; q2048_table_grow maps the next capacity onto fresh
+// physical chunks, moves the rows over and releases the smaller table's chunks -- so every address of
+// the range is mapped at most ONCE in the life of the process, and the range itself is never freed.
+// That is the rule the round-3 trap taught (below); it also means a table's address changes when it grows.
 namespace {
-struct ChunkedTable { size_t bytes, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+struct Family { char* base; size_t bytes, chunk; int dev, cap0_log2, max_log2; };
+struct ChunkedTable { size_t bytes; int cap_log2; Family* fam; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_tables_mutex;
 std::map<void*, ChunkedTable> g_tables;
+std::vector<Family*> g_families;                         // kept for the life of the process (see release_chunks)
+
+size_t table_bytes(const Family& f, int cap_log2) {
+  const size_t want = sizeof(q2048_slot) << cap_log2;
+  return (want + f.chunk - 1) / f.chunk * f.chunk;
+}
+size_t family_offset(const Family& f, int cap_log2) {
+  size_t off = 0;
+  for (int k = f.cap0_log2; k < cap_log2; ++k) off += table_bytes(f, k);
+  return off;
+}
 // Freeing: every chunk is unmapped (one by one, as it was mapped) and its physical memory released;
 // the ADDRESS RANGE is kept reserved for the life of the process and never handed out again.  On
 // this stack (ROCm 7.2) a range that is freed, reserved again and mapped onto new physical chunks
@@ -2347,19 +2437,85 @@ std::map<void*, ChunkedTable> g_tables;
 // process lost 1-15 % of its rows (inserts != occupied slots, 5x5 claims timing out;
 // tools/chunk_debug.py reproduces it in seconds, and with fresh addresses every table is exact).
 // Virtual addresses are not scarce (a 32 GiB table uses 2^-12 of a 47-bit space).
-int release_chunks(void* va, ChunkedTable& t, size_t mapped) {
+int release_chunks(void* va, size_t chunk, std::vector<hipMemGenericAllocationHandle_t>& handles, size_t mapped) {
   int bad = 0;
   for (size_t k = 0; k < mapped; ++k)
-    bad += hipMemUnmap(static_cast<char*>(va) + k * t.chunk, t.chunk) != hipSuccess;
-  for (auto& h : t.handles) bad += hipMemRelease(h) != hipSuccess;
+    bad += hipMemUnmap(static_cast<char*>(va) + k * chunk, chunk) != hipSuccess;
+  for (auto& h : handles) bad += hipMemRelease(h) != hipSuccess;
+  handles.clear();
   return bad;
+}
+// RAII: the calling thread's current device while a table of another device is worked on
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+// occupied slots of a table, host-synchronous (a 16-byte device scratch per call)
+int count_rows_sync(const q2048_slot* table, int cap_log2, uint64_t* rows) {
+  u64* d = nullptr;
+  if (hipMalloc(&d, 16) != hipSuccess) return Q2048_ERR_ALLOC;
+  int rc = Q2048_OK;
+  if (hipMemset(d, 0, 16) != hipSuccess) rc = Q2048_ERR_LAUNCH;
+  if (rc == Q2048_OK) rc = q2048_table_count(table, cap_log2, reinterpret_cast<int64_t*>(d), nullptr);
+  unsigned long long v = 0;
+  if (rc == Q2048_OK && hipMemcpy(&v, d, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = Q2048_ERR_LAUNCH;
+  (void)hipFree(d);
+  *rows = (uint64_t)v;
+  return rc;
+}
+// maps, zero-fills and verifies the table of capacity 2^cap_log2 of a family; registers it
+int map_table(Family* f, int cap_log2, q2048_slot** out) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = f->dev;
+  ChunkedTable t;
+  t.bytes = table_bytes(*f, cap_log2);
+  t.cap_log2 = cap_log2;
+  t.fam = f;
+  char* va = f->base + family_offset(*f, cap_log2);
+  const size_t n = t.bytes / f->chunk;
+  t.handles.reserve(n);
+  size_t mapped = 0;
+  for (size_t k = 0; k < n; ++k) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, f->chunk, &prop, 0) != hipSuccess) { release_chunks(va, f->chunk, t.handles, mapped); return Q2048_ERR_ALLOC; }
+    t.handles.push_back(h);
+    if (hipMemMap(va + k * f->chunk, f->chunk, 0, h, 0) != hipSuccess) {
+      release_chunks(va, f->chunk, t.handles, mapped);
+      return Q2048_ERR_ALLOC;
+    }
+    ++mapped;
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if (hipMemSetAccess(va, t.bytes, &acc, 1) != hipSuccess || hipMemset(va, 0, t.bytes) != hipSuccess) {
+    release_chunks(va, f->chunk, t.handles, mapped);
+    return Q2048_ERR_ALLOC;
+  }
+  // Silent row loss is the worst failure this library can have, and a table that does not read back as
+  // zeros is how it would start (a slot that looks occupied swallows a key's probe sequence; stale
+  // translations were seen once, above): one streaming count of the fresh table, ~5 ms per 32 GiB.
+  uint64_t rows = 0;
+  int rc = count_rows_sync(reinterpret_cast<q2048_slot*>(va), cap_log2, &rows);
+  if (rc == Q2048_OK && rows != 0) rc = Q2048_ERR_VERIFY;
+  if (rc != Q2048_OK) { release_chunks(va, f->chunk, t.handles, mapped); return rc; }
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
+  g_tables.emplace(va, std::move(t));
+  *out = reinterpret_cast<q2048_slot*>(va);
+  return Q2048_OK;
 }
 }  // namespace
 
-int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot** table_out) {
+int q2048_table_reserve(int cap_log2, int max_cap_log2, size_t chunk_bytes, q2048_slot** table_out) {
   if (table_out == nullptr) return Q2048_ERR_NULL;
   *table_out = nullptr;
-  if (cap_log2 < 4 || cap_log2 > 40) return Q2048_ERR_SIZE;
+  if (cap_log2 < 4 || cap_log2 > 40 || max_cap_log2 < cap_log2 || max_cap_log2 > 40) return Q2048_ERR_SIZE;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return Q2048_ERR_LAUNCH;
   hipMemAllocationProp prop = {};
@@ -2369,36 +2525,71 @@ int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot** table_out) 
   size_t gran = 0;
   if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0)
     return Q2048_ERR_ALLOC;
-  ChunkedTable t;
-  t.chunk = chunk_bytes ? chunk_bytes : ((size_t)2 << 20);
-  if (t.chunk % gran != 0) return Q2048_ERR_SIZE;
-  const size_t want = sizeof(q2048_slot) << cap_log2;
-  t.bytes = (want + t.chunk - 1) / t.chunk * t.chunk;
+  Family* f = new Family{nullptr, 0, chunk_bytes ? chunk_bytes : ((size_t)2 << 20), dev, cap_log2, max_cap_log2};
+  if (f->chunk % gran != 0) { delete f; return Q2048_ERR_SIZE; }
+  f->bytes = family_offset(*f, max_cap_log2 + 1);
   void* va = nullptr;
-  if (hipMemAddressReserve(&va, t.bytes, t.chunk, nullptr, 0) != hipSuccess) return Q2048_ERR_ALLOC;
-  const size_t n = t.bytes / t.chunk;
-  t.handles.reserve(n);
-  size_t mapped = 0;
-  for (size_t k = 0; k < n; ++k) {
-    hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, t.chunk, &prop, 0) != hipSuccess) { release_chunks(va, t, mapped); return Q2048_ERR_ALLOC; }
-    t.handles.push_back(h);
-    if (hipMemMap(static_cast<char*>(va) + k * t.chunk, t.chunk, 0, h, 0) != hipSuccess) {
-      release_chunks(va, t, mapped);
-      return Q2048_ERR_ALLOC;
-    }
-    ++mapped;
-  }
-  hipMemAccessDesc acc = {};
-  acc.location = prop.location;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  if (hipMemSetAccess(va, t.bytes, &acc, 1) != hipSuccess || hipMemset(va, 0, t.bytes) != hipSuccess) {
-    release_chunks(va, t, mapped);
-    return Q2048_ERR_ALLOC;
+  if (hipMemAddressReserve(&va, f->bytes, f->chunk, nullptr, 0) != hipSuccess) { delete f; return Q2048_ERR_ALLOC; }
+  f->base = static_cast<char*>(va);
+  const int rc = map_table(f, cap_log2, table_out);
+  if (rc != Q2048_OK) {
+    // nothing on the device has touched the range yet when the failure is an allocation failure: hand it
+    // back.  After a failed VERIFY it has been read: kept, like every range that was ever used.
+    if (rc != Q2048_ERR_VERIFY && hipMemAddressFree(va, f->bytes) == hipSuccess) { delete f; return rc; }
   }
   std::lock_guard<std::mutex> lock(g_tables_mutex);
-  g_tables.emplace(va, std::move(t));
-  *table_out = static_cast<q2048_slot*>(va);
+  g_families.push_back(f);
+  return rc;
+}
+
+int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot** table_out) {
+  return q2048_table_reserve(cap_log2, cap_log2, chunk_bytes, table_out);
+}
+
+int q2048_table_grow(q2048_slot* table, int cap_log2, int new_cap_log2, int key_words, q2048_slot** table_out,
+                     int64_t* rows_moved, void* stream) {
+  if (table == nullptr || table_out == nullptr) return Q2048_ERR_NULL;
+  *table_out = nullptr;
+  if (key_words != 1 && key_words != 2) return Q2048_ERR_SIZE;
+  Family* f = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    auto it = g_tables.find(table);
+    if (it == g_tables.end()) return Q2048_ERR_NULL;      // not one of q2048_table_reserve's
+    if (it->second.cap_log2 != cap_log2) return Q2048_ERR_SIZE;
+    f = it->second.fam;
+  }
+  if (new_cap_log2 <= cap_log2 || new_cap_log2 > f->max_log2) return Q2048_ERR_SIZE;
+  DeviceGuard guard(f->dev);
+  q2048_slot* bigger = nullptr;
+  if (int e = map_table(f, new_cap_log2, &bigger)) return e;
+  u64* counters = nullptr;
+  int rc = hipMalloc(&counters, 16) == hipSuccess ? Q2048_OK : Q2048_ERR_ALLOC;
+  unsigned long long host[2] = {0ull, 0ull};
+  if (rc == Q2048_OK && hipMemsetAsync(counters, 0, 16, (hipStream_t)stream) != hipSuccess) rc = Q2048_ERR_LAUNCH;
+  if (rc == Q2048_OK) {
+    // ordered on `stream` behind whatever still works on the old table; 8 blocks of 4 waves per CU
+    const u64 cap = 1ull << cap_log2, mask = (1ull << new_cap_log2) - 1ull;
+    const u64 want = (cap + kBlock - 1) / kBlock;
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    if (key_words == 1)
+      hipLaunchKernelGGL(k_table_rehash<1>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, table, cap, bigger, mask, counters);
+    else
+      hipLaunchKernelGGL(k_table_rehash<2>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, table, cap, bigger, mask, counters);
+    rc = launch_status();
+  }
+  if (rc == Q2048_OK && (hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+                         hipStreamSynchronize((hipStream_t)stream) != hipSuccess))
+    rc = Q2048_ERR_LAUNCH;
+  if (counters != nullptr) (void)hipFree(counters);
+  // every row must have moved, and the new table must hold exactly those rows
+  uint64_t rows = 0;
+  if (rc == Q2048_OK) rc = count_rows_sync(bigger, new_cap_log2, &rows);
+  if (rc == Q2048_OK && (host[1] != 0ull || rows != (uint64_t)host[0])) rc = Q2048_ERR_VERIFY;
+  if (rc != Q2048_OK) { q2048_table_free(bigger); return rc; }   // the old table is intact and stays the caller's
+  if (rows_moved != nullptr) *rows_moved = (int64_t)host[0];
+  if (int e = q2048_table_free(table)) return e;
+  *table_out = bigger;
   return Q2048_OK;
 }
 
@@ -2408,12 +2599,13 @@ int q2048_table_free(q2048_slot* table) {
   {
     std::lock_guard<std::mutex> lock(g_tables_mutex);
     auto it = g_tables.find(table);
-    if (it == g_tables.end()) return Q2048_ERR_NULL;      // not one of q2048_table_alloc's
+    if (it == g_tables.end()) return Q2048_ERR_NULL;      // not one of q2048_table_reserve's
     t = std::move(it->second);
     g_tables.erase(it);
   }
+  DeviceGuard guard(t.fam->dev);                          // the table's device, whatever the caller's current one is
   if (hipDeviceSynchronize() != hipSuccess) return Q2048_ERR_LAUNCH;
-  return release_chunks(table, t, t.handles.size()) ? Q2048_ERR_ALLOC : Q2048_OK;
+  return release_chunks(table, t.fam->chunk, t.handles, t.handles.size()) ? Q2048_ERR_ALLOC : Q2048_OK;
 }
 
 int q2048_table_count(const q2048_slot* table, int cap_log2, int64_t* count, void* stream) {

@@ -58,7 +58,7 @@ class BatchedGame2048Env:
 
     def __init__(self, num_envs: int, board_size: int = 4, device="cuda", seed: int = 0,
                  env_id0: int = 0, profile: str = "shaped", reset_shaping_state: bool = False,
-                 host_visible: bool = False):
+                 host_visible: bool = False, copy_outputs: bool = False):
         """profile  "shaped" = Game2048_env of QLearningBase (the hot path's env);
                     "nopenalty" = the DQN path's Game2048_env,
                     Deep_QLearning/environment/Game2048_nopenalty_env.py: reward =
@@ -70,8 +70,16 @@ class BatchedGame2048Env:
                     restore them to their constructor values.  Default: the reference's behaviour.
         host_visible  keep boards / aux / outputs in pinned host memory that the kernels address
                     directly (the one-env adapter: a step is one launch and one synchronisation,
-                    no copies).  For a handful of envs only: every access crosses PCIe."""
+                    no copies).  For a handful of envs only: every access crosses PCIe.
+        copy_outputs  `step` returns fresh reward / done / max_tile tensors instead of views of the
+                    env's own output buffers.  Default off (since round 3): the views are what keeps
+                    every torch kernel out of the batched loop, and the loop of Agent/main.py:92-100
+                    consumes a step's outputs before the next step; a caller that KEEPS them across
+                    steps (a list of rewards, a comparison with the previous `done`) must turn this on
+                    or clone.  `boards` is always one of two ping-pong buffers: the tensor returned by
+                    step t is overwritten by step t + 2."""
         self.device = _require_gpu(device)
+        self.copy_outputs = bool(copy_outputs)
         if board_size not in (4, 5):
             raise NotImplementedError("board_size must be 4 (the reference) or 5")
         if num_envs <= 0:
@@ -141,6 +149,8 @@ class BatchedGame2048Env:
         self.ctr += 1
         if self.host_visible:                           # host tensors: the launch has to finish first
             torch.cuda.current_stream(self.device).synchronize()
+        if self.copy_outputs:
+            return self.boards, self._reward.clone(), self._done.view(torch.bool).clone(), self._max_tile.clone()
         return self.boards, self._reward, self._done.view(torch.bool), self._max_tile
 
     @property

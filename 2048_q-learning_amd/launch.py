@@ -57,14 +57,27 @@ def rank_env(rank: int, world_size: int, master_addr: str, master_port: int, bas
     return env
 
 
-def _die_with_parent():
+# libc.prctl, resolved ONCE, here, in the parent: the child must not dlopen between fork and exec (if
+# another thread of the launcher held the loader's or malloc's lock at fork time, the child would
+# wait for it forever -- the launcher runs under pytest and inside callers that have threads)
+try:
+    _PRCTL = ctypes.CDLL(None, use_errno=True).prctl
+except Exception:                                                       # not Linux: nothing to set
+    _PRCTL = None
+
+
+def _die_with_parent_of(parent_pid: int):
     """preexec_fn of the rank processes (Linux): SIGTERM when the launcher dies, however it dies --
     a rank blocked in a collective would otherwise keep its GPU and its multi-GiB table until the
-    c10d timeout."""
-    try:
-        ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGTERM)      # PR_SET_PDEATHSIG
-    except Exception:                                                   # not Linux: nothing to set
-        pass
+    c10d timeout.  Between fork and exec it only calls what was resolved beforehand; a launcher that
+    died before the prctl took effect is noticed by its changed parent pid."""
+    def preexec():
+        if _PRCTL is None:
+            return
+        _PRCTL(1, int(signal.SIGTERM))                                  # PR_SET_PDEATHSIG
+        if os.getppid() != parent_pid:                                  # the launcher is gone already
+            os.kill(os.getpid(), signal.SIGTERM)
+    return preexec
 
 
 def _stop(procs, grace_s: float = 5.0) -> None:
@@ -123,7 +136,7 @@ def launch_ranks(argv, nproc: int, master_addr: str = "127.0.0.1", master_port: 
             procs.append(subprocess.Popen(
                 list(argv), env=rank_env(r, nproc, master_addr, port, env),
                 stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True,
-                preexec_fn=_die_with_parent))
+                preexec_fn=_die_with_parent_of(os.getpid())))
 
         def relay():
             for line in procs[0].stdout:
@@ -149,9 +162,15 @@ def launch_ranks(argv, nproc: int, master_addr: str = "127.0.0.1", master_port: 
     except _Signalled as sig:
         failed, worst = True, 128 + int(sig.args[0])
     finally:
-        _stop(procs)                          # exactly the PIDs started above; a no-op when all have exited
-        for sig, h in old_handlers.items():
-            signal.signal(sig, h)
+        # a second SIGTERM / SIGINT while the ranks are being stopped must not abort the stopping: the
+        # signals are ignored for its duration, then the caller's handlers come back
+        for sig in old_handlers:
+            signal.signal(sig, signal.SIG_IGN)
+        try:
+            _stop(procs)                      # exactly the PIDs started above; a no-op when all have exited
+        finally:
+            for sig, h in old_handlers.items():
+                signal.signal(sig, h)
     if pump is not None:
         pump.join(timeout=5.0)
     if failed:

@@ -293,7 +293,9 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
         assert st["episodes"] > 0, "no episode finished inside a timed region: reset path unmeasured"
         regions.append({"wall_s": wall, "kernel_ms": ev0.elapsed_time(ev1), "launches": launches, "stats": st})
     if mirrored:                                     # the mirror against the device vectors themselves
-        assert pkg.stats_dict(*agent.mirrored_stats()) == agent.stats(), "statistics mirror != device vectors"
+        mi, mf = agent.mirrored_stats()
+        assert (mi == agent.stats_i.cpu().numpy()).all() and (mf == agent.stats_f.cpu().numpy()).all(), \
+            "statistics mirror != device vectors"
     worst = pkg.dist.max_over_ranks_many([r["wall_s"] for r in regions] + [r["kernel_ms"] for r in regions],
                                          device=dev)
     for k, r in enumerate(regions):

@@ -11,8 +11,10 @@
  *
  * Conventions
  *   - Plain pointers and sizes only.  Every data pointer is a DEVICE pointer (HIP); the caller
- *     owns all memory (the library never allocates); `stream` is a hipStream_t (NULL = default
- *     stream).  All calls are asynchronous and stream-ordered: no host synchronisation inside.
+ *     owns all memory -- the library allocates nothing, with one exception the caller asks for by
+ *     name: q2048_table_alloc / _reserve / _grow / _free (a Q-table mapped from 2 MiB physical
+ *     chunks; host-synchronous).  `stream` is a hipStream_t (NULL = default stream).  All other
+ *     calls are asynchronous and stream-ordered: no host synchronisation inside.
  *   - boards   uint8_t[B][16]: 4x4 board, row-major, log2 tiles (0 empty, k = tile 2^k), the
  *              device image of the reference's np.int64[4,4] raw-value board
  *              (Game2048_env.py:12).  16-byte aligned.
@@ -57,6 +59,8 @@ extern "C" {
 #define Q2048_ERR_RANGE (-6)       /* a scalar is outside its domain (eps, lr, gamma) */
 #define Q2048_ERR_FLAGS (-7)       /* flag bits outside the ABI, or flags the entry point refuses */
 #define Q2048_ERR_ALLOC (-8)       /* q2048_table_alloc: memory could not be reserved / created / mapped */
+#define Q2048_ERR_VERIFY (-9)      /* a table failed its self-check: a freshly mapped table did not read back as
+                                      zeros, or q2048_table_grow did not find every row in the new table */
 
 /* bits of the device status word */
 #define Q2048_STATUS_BAD_ACTION 1u    /* an action outside 0..3 was passed (lane left untouched) */
@@ -369,12 +373,37 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  * takes them 15-20 % faster than a hipMalloc of the same 8-32 GiB (load + compare-and-swap + store
  * per lane-step: 46.2 against 55.4 us per 2^20 on an 8 GiB table, 51.2 with 64 MiB chunks;
  * profiles/r03_requests/vmm_*_8GiB.txt; loads do not care) -- as fast as a table that spans 128 GiB.
+ *
  * q2048_table_alloc reserves, creates, maps and zero-fills 2^cap_log2 slots (chunk_bytes = 0: 2 MiB;
- * else a multiple of the allocation granularity) on the current device and is host-synchronous;
- * q2048_table_free unmaps the chunks and releases their physical memory (it synchronises the device
- * first); the table's virtual address range stays reserved until the process ends -- a re-used
- * range was seen to serve stale translations on ROCm 7.2.  Both are thread-safe. */
+ * else a multiple of the allocation granularity) on the current device, and VERIFIES the zero fill
+ * with one streaming count of the table before it returns (Q2048_ERR_VERIFY otherwise: a slot that
+ * wrongly looks occupied is how rows would get lost silently).  Host-synchronous.
+ *
+ * A table that grows -- the reference's defaultdict (Agent/main.py:16) has no capacity:
+ * q2048_table_reserve reserves the address range of every capacity from cap_log2 to max_cap_log2 at
+ * once (less than 2 x the largest table; address space only) and maps the first;
+ * q2048_table_grow(table, cap_log2, new_cap_log2, key_words, &bigger, &rows, stream) maps the table of
+ * capacity 2^new_cap_log2 (cap_log2 < new_cap_log2 <= max_cap_log2) onto fresh chunks further along the
+ * range, moves every row over in one streaming pass ordered on `stream` (the rows keep their values;
+ * their slots change: zero-fill any row cache), checks that the new table holds exactly the rows
+ * the old one held (Q2048_ERR_VERIFY otherwise: the old table is then intact and still the caller's), and
+ * releases the old table.  The table's ADDRESS changes: *table_out is the table from then on.
+ * rows_moved (host int64, may be NULL) receives the number of rows.  Host-synchronous; while both
+ * tables exist the device holds 1.5 x the new one.  The caller decides when: between launches, when
+ * rows created / capacity passes its load limit (the rollout's step slows from 46.7 to 66.3 us as the
+ * load goes from 0.12 to 0.54, profiles/r03_load_curve.jsonl).
+ *
+ * q2048_table_free unmaps a table's chunks and releases their physical memory (it synchronises the
+ * table's device first, whatever the calling thread's current device is).  THE ADDRESS RANGE STAYS
+ * RESERVED until the process ends and no part of it is ever mapped a second time -- a range that was
+ * freed, reserved again and mapped onto new chunks was seen to serve stale translations on ROCm 7.2
+ * (the third table of a process lost 1-15 % of its rows; tools/chunk_debug.py).  A process therefore
+ * accumulates reserved address space -- 2^-12 of its 47-bit space per 32 GiB table -- not memory.
+ * All four are thread-safe. */
 int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot **table_out);
+int q2048_table_reserve(int cap_log2, int max_cap_log2, size_t chunk_bytes, q2048_slot **table_out);
+int q2048_table_grow(q2048_slot *table, int cap_log2, int new_cap_log2, int key_words,
+                     q2048_slot **table_out, int64_t *rows_moved, void *stream);
 int q2048_table_free(q2048_slot *table);
 
 /* Placement probe (no reference counterpart): `lanes` lanes each issue `steps` scattered

@@ -561,7 +561,7 @@ void orc_rollout_ex(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t step
         if (stats_i) {
           stats_i[ORC_ST_EPISODES] += 1;
           stats_i[ORC_ST_SCORE] += e->score;
-          stats_i[ORC_ST_HIST0 + (mx > 23 ? 23 : mx)] += 1;
+          stats_i[ORC_ST_HIST0 + (mx > 22 ? 22 : mx)] += 1;   /* slots 8..30; 31 is the device's CAS-fallback counter */
         }
         if (stats_f) {
           stats_f[ORC_SF_RETURN] += e->episode_return;
@@ -610,7 +610,7 @@ void orc_rollout_sync(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t st
       if (done) {
         if (stats_i) {
           stats_i[ORC_ST_EPISODES] += 1; stats_i[ORC_ST_SCORE] += e->score;
-          stats_i[ORC_ST_HIST0 + (mx > 23 ? 23 : mx)] += 1;
+          stats_i[ORC_ST_HIST0 + (mx > 22 ? 22 : mx)] += 1;   /* slots 8..30; 31 is the device's CAS-fallback counter */
         }
         if (stats_f) {
           stats_f[ORC_SF_RETURN] += e->episode_return;
@@ -756,7 +756,7 @@ void orc_rt_rollout(orc_env_t *envs, int64_t B, float *w, int64_t steps, double 
         if (stats_i) {
           stats_i[ORC_ST_EPISODES] += 1;
           stats_i[ORC_ST_SCORE] += e->score;
-          stats_i[ORC_ST_HIST0 + (mx > 23 ? 23 : mx)] += 1;
+          stats_i[ORC_ST_HIST0 + (mx > 22 ? 22 : mx)] += 1;   /* slots 8..30; 31 is the device's CAS-fallback counter */
         }
         if (stats_f) {
           stats_f[ORC_SF_RETURN] += e->episode_return;

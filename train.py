@@ -47,7 +47,9 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--device", default="cuda")
     p.add_argument("--steps-per-launch", type=int, default=64)
-    p.add_argument("--capacity-log2", type=int, default=0, help="Q-table slots = 2^n (0 = auto)")
+    p.add_argument("--capacity-log2", type=int, default=0,
+                   help="Q-table slots = 2^n, fixed; 0 (default) = a table that grows like the reference's "
+                        "defaultdict: it starts at 2^28 slots and doubles whenever half of it is in use")
     p.add_argument("--strict-td", action="store_true", help="compare-and-swap TD writes (bounded: after 16 lost "
                    "races an update is stored plainly and counted in the statistics)")
     p.add_argument("--deterministic", action="store_true",
@@ -148,11 +150,9 @@ def train_batched(args, pkg):
     torch.cuda.set_device(dev)
     shard = pkg.weak_shard(args.num_envs, world, rank)
     B = shard.num_envs
-    # ~220 steps per episode, most of them reach a new state: size for the whole run (load <= 0.5),
-    # capped at 2^32 slots = 128 GiB
-    rows_per_episode = 256 if args.board_size == 4 else 2048     # 5x5 games last several times longer
-    cap = args.capacity_log2 or int(min(32, max(20, np.ceil(np.log2(2.0 * B * rows_per_episode *
-                                                                   max(args.episodes, 1))))))
+    # the reference's q_table is a defaultdict (Agent/main.py:16): no capacity to choose.  Without
+    # --capacity-log2 the device table grows as the run goes (BatchedQLearningAgent(capacity_log2="auto"))
+    cap = args.capacity_log2 or "auto"
     env = pkg.BatchedGame2048Env(B, args.board_size, dev, args.seed, shard.env_id0,
                                  profile=args.env_profile, reset_shaping_state=args.reset_shaping_state)
     reducer = pkg.StatsAllReduce(dev)                 # the only collective, on a stream of its own
@@ -199,7 +199,7 @@ def train_batched(args, pkg):
         total_eps = pkg.stats_dict(*reducer.wait())["episodes"]
     stop_epoch = min(args.episodes, args.stop_epoch) if args.stop_epoch else args.episodes
     target = stop_epoch * shard.total_envs
-    best_tile = 0
+    best_tile, grown = 0, 0
     agent.train_progress = {"epoch": epoch}
     agent.train_env = env
     while total_eps < target:
@@ -225,6 +225,13 @@ def train_batched(args, pkg):
             epoch += 1
         agent.train_progress = {"epoch": epoch}
         best_tile = max(st["max_tile_hist"], default=0)
+        if args.agent == "hash":
+            check = agent.verify_table()                  # occupied slots == rows the kernels created: every report
+            while len(agent.growths) > grown:
+                g = agent.growths[grown]
+                grown += 1
+                print(f"[rank {rank}] table grew 2^{g['from_log2']} -> 2^{g['to_log2']} slots at step "
+                      f"{g['at_step']}: {g['rows']} rows moved in {g['ms']:.1f} ms", flush=True)
         if rank == 0:
             rate = st["steps"] / (time.time() - t0)
             with open(args.log, mode="a", newline="") as fh:
