@@ -40,10 +40,15 @@ constexpr uint32_t kStreamStep = 0u, kStreamReset = 1u, kStreamOver = 2u;
 
 struct Draws { uint32_t x0, x1, x2, x3; };
 
+// (Q2048_PHILOX_ROUNDS: measurement builds only -- tools/sessions/r04_philox7.sh times the rollouts with
+// Philox4x32-7, the smallest variant that passes BigCrush, against the 10 rounds of the draw contract.)
+#ifndef Q2048_PHILOX_ROUNDS
+#define Q2048_PHILOX_ROUNDS 10
+#endif
 Q_HD Draws philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                          uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < Q2048_PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

@@ -16,6 +16,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -2605,6 +2607,27 @@ int q2048_table_free(q2048_slot* table) {
   }
   DeviceGuard guard(t.fam->dev);                          // the table's device, whatever the caller's current one is
   if (hipDeviceSynchronize() != hipSuccess) return Q2048_ERR_LAUNCH;
+#ifdef Q2048_EXPERIMENTS
+  // Measurement builds only (tools/chunk_debug.py): the round-3 free path that handed the address range
+  // back, to look for what goes wrong when a range is re-used.  Q2048_DEBUG_VA_FREE = 1: unmap, release,
+  // hipMemAddressFree; 2: the same and a device synchronize after it; 3: hipMemAddressFree only after
+  // every chunk's hipMemRelease returned success, return codes printed.  Families of one table only.
+  if (const char* mode = getenv("Q2048_DEBUG_VA_FREE")) {
+    if (t.fam->cap0_log2 == t.fam->max_log2) {
+      const int m = atoi(mode);
+      int bad_unmap = 0, bad_release = 0;
+      for (size_t k = 0; k < t.handles.size(); ++k)
+        bad_unmap += hipMemUnmap(reinterpret_cast<char*>(table) + k * t.fam->chunk, t.fam->chunk) != hipSuccess;
+      for (auto& h : t.handles) bad_release += hipMemRelease(h) != hipSuccess;
+      const hipError_t fr = hipMemAddressFree(t.fam->base, t.fam->bytes);
+      const hipError_t sy = m >= 2 ? hipDeviceSynchronize() : hipSuccess;
+      if (m >= 3)
+        fprintf(stderr, "[q2048 debug] free %p: %zu chunks, unmap errors %d, release errors %d, AddressFree %d, sync %d\n",
+                (void*)table, t.handles.size(), bad_unmap, bad_release, (int)fr, (int)sy);
+      return (bad_unmap || bad_release || fr != hipSuccess) ? Q2048_ERR_ALLOC : Q2048_OK;
+    }
+  }
+#endif
   return release_chunks(table, t.fam->chunk, t.handles, t.handles.size()) ? Q2048_ERR_ALLOC : Q2048_OK;
 }
 

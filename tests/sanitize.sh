@@ -1,14 +1,35 @@
 #!/usr/bin/env bash
-# CPU-only sanitizer pass (GPU sanitizers are not available on the pool): UBSan builds of the
-# oracle and of the host instantiation of csrc/q2048_core*.hpp, then the suites that use them.
+# CPU-only sanitizer pass (GPU sanitizers are not available on the pool), three legs:
+#   1. UBSan builds of the oracle and of the host instantiation of csrc/q2048_core*.hpp under the suites
+#      that use them (tests/test_oracle_golden.py, tests/test_core_host.py);
+#   2. the same two libraries under AddressSanitizer (the runtime preloaded into the interpreter);
+#   3. ThreadSanitizer on the oracle's one multi-threaded function, orc_rollout_mt (the CPU baseline
+#      bench.py times), through a small C driver (tests/sanitizers/tsan_rollout_mt.c).
+# Usage: bash tests/sanitize.sh [log file]   (the log of the round is committed under profiles/)
 set -e
 cd "$(dirname "$0")/.."
-SAN="-fsanitize=undefined -fno-sanitize-recover=undefined"
-gcc -O1 -g -fPIC -std=c11 -ffp-contract=off $SAN -shared -o /tmp/liboracle_ubsan.so oracle/q2048_oracle.c -lm -lpthread
-g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off $SAN -I 2048_q-learning_amd/csrc -o /tmp/libhostcheck_ubsan.so tests/hostcheck/hostcheck.cpp
+LOG=${1:-/tmp/sanitize.log}
+: > "$LOG"
+say() { echo "$@" | tee -a "$LOG"; }
 python -c "from oracle import oracle; oracle.build()"; python -m pytest tests/test_core_host.py -q -k luts >/dev/null
 cp oracle/liboracle.so /tmp/liboracle_keep.so; cp tests/hostcheck/libhostcheck.so /tmp/libhostcheck_keep.so
 trap 'cp /tmp/liboracle_keep.so oracle/liboracle.so; cp /tmp/libhostcheck_keep.so tests/hostcheck/libhostcheck.so; touch oracle/liboracle.so tests/hostcheck/libhostcheck.so' EXIT
-cp /tmp/liboracle_ubsan.so oracle/liboracle.so; cp /tmp/libhostcheck_ubsan.so tests/hostcheck/libhostcheck.so
-touch oracle/liboracle.so tests/hostcheck/libhostcheck.so
-python -m pytest tests/test_oracle_golden.py tests/test_core_host.py -q
+leg() {   # leg <name> <sanitizer flags> <env assignments for pytest...>
+  local name=$1 san=$2; shift 2
+  gcc -O1 -g -fPIC -std=c11 -ffp-contract=off -fno-omit-frame-pointer $san -shared -o /tmp/liboracle_$name.so oracle/q2048_oracle.c -lm -lpthread
+  g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fno-omit-frame-pointer $san -I 2048_q-learning_amd/csrc -o /tmp/libhostcheck_$name.so tests/hostcheck/hostcheck.cpp
+  cp /tmp/liboracle_$name.so oracle/liboracle.so; cp /tmp/libhostcheck_$name.so tests/hostcheck/libhostcheck.so
+  touch oracle/liboracle.so tests/hostcheck/libhostcheck.so
+  say "== $name: pytest tests/test_oracle_golden.py tests/test_core_host.py ($san)"
+  env "$@" python -m pytest tests/test_oracle_golden.py tests/test_core_host.py -q -p no:cacheprovider 2>&1 | tail -n 3 | tee -a "$LOG"
+  test "${PIPESTATUS[0]}" -eq 0
+}
+leg ubsan "-fsanitize=undefined -fno-sanitize-recover=undefined"
+# ASan: the interpreter is not instrumented, so the runtime is preloaded; CPython's own arenas are not
+# the subject (detect_leaks=0), every access of the two libraries is
+leg asan "-fsanitize=address" LD_PRELOAD="$(gcc -print-file-name=libasan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1
+say "== tsan: orc_rollout_mt (4 threads, private agents) against the sequential run"
+gcc -O1 -g -std=c11 -ffp-contract=off -fsanitize=thread -o /tmp/tsan_rollout_mt tests/sanitizers/tsan_rollout_mt.c oracle/q2048_oracle.c -lm -lpthread
+TSAN_OPTIONS=halt_on_error=1 /tmp/tsan_rollout_mt 2>&1 | tee -a "$LOG"
+test "${PIPESTATUS[0]}" -eq 0
+say "sanitize.sh: all three legs clean"

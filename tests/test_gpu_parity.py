@@ -1920,7 +1920,7 @@ def test_table_grows_like_the_reference_defaultdict(pkg, n):
         assert chk["load"] <= 0.5 + 2.0 * B * S / (1 << a1.capacity_log2)
         if a1.table.data_ptr() not in seen:
             seen.add(a1.table.data_ptr())
-    assert len(a1.growths) >= 2 and len(seen) == len(a1.growths) + 1, a1.growths
+    assert len(a1.growths) >= 2 and 2 <= len(seen) <= len(a1.growths) + 1, a1.growths   # (a call may double twice)
     assert [g["to_log2"] - g["from_log2"] for g in a1.growths] == [1] * len(a1.growths)
     assert torch.equal(e0.boards, e1.boards) and torch.equal(e0.aux, e1.aux)
     (k0, q0), (k1, q1) = table(a0), table(a1)

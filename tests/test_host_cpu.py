@@ -102,6 +102,28 @@ def test_header_structs_match_numpy_layout(pkg):
     assert [pkg.AUX_DTYPE.fields[k][1] for k in pkg.AUX_DTYPE.names] == [0, 4, 8, 9, 10, 12]
 
 
+def test_rollout_opts_struct_matches_the_header(pkg, tmp_path):
+    """_native.RolloutOpts (ctypes) against q2048_rollout_opts as a C compiler lays it out from
+    include/q2048.h: size and every field offset; and the mirror's word count."""
+    import ctypes as C
+    import subprocess
+
+    N = pkg._native
+    fields = [f[0] for f in N.RolloutOpts._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "q2048.h"\nint main(void) {\n'
+                   '  printf("%zu %d %d", sizeof(q2048_rollout_opts), Q2048_MIRROR_SEQ, Q2048_MIRROR_WORDS);\n'
+                   + "".join(f'  printf(" %zu", offsetof(q2048_rollout_opts, {f}));\n' for f in fields)
+                   + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), "-o", str(exe), str(src)],
+                   check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got[0] == C.sizeof(N.RolloutOpts) and got[1] == N.MIRROR_SEQ and got[2] == N.MIRROR_WORDS
+    assert got[3:] == [getattr(N.RolloutOpts, f).offset for f in fields]
+    assert N.RolloutOpts().size == got[0]
+
+
 def test_product_fails_loudly_without_gpu(pkg):
     import torch
 
@@ -240,11 +262,17 @@ envs = O.envs_init(shard.num_envs, 4, seed, shard.env_id0)
 agent = O.Agent(100, 4, 0.1, 0.9, 1.0)               # eps = 1: trajectories independent of Q
 si, sf = O.rollout(envs, agent, steps, seed, shard.env_id0, 0)
 ti, tf = torch.from_numpy(si.copy()), torch.from_numpy(sf.copy())
+reducer = pkg.StatsAllReduce(None)                  # the one-collective form bench.py / train.py use
+reducer.start(ti, tf)
+ti[0] += 1000                                        # after the snapshot
+gi, gf = reducer.wait()
+ti[0] -= 1000
 pkg.allreduce_stats(ti, tf)
 slowest = pkg.dist.max_over_ranks(float(rank + 1))
+many = pkg.dist.max_over_ranks_many([float(rank), float(10 - rank), 3.5])
 pkg.dist.barrier()
 np.savez(sys.argv[5] + f".{rank}.npz", boards=envs["board"][:, :16], si=ti.numpy(), sf=tf.numpy(),
-         local_si=si, id0=shard.env_id0, slowest=slowest)
+         local_si=si, id0=shard.env_id0, slowest=slowest, gi=gi, gf=gf, many=np.array(many))
 dist.destroy_process_group()
 '''
 
@@ -271,7 +299,9 @@ def test_world_size_2_gloo_sharding_and_stats_allreduce(pkg, O, tmp_path):
             assert p["si"][k] == si[k], k
         assert np.array_equal(p["si"][O.ST_HIST0:], si[O.ST_HIST0:])
         assert np.allclose(p["sf"], sf, rtol=1e-12)
-        assert p["slowest"] == 2.0
+        assert p["slowest"] == 2.0 and p["many"].tolist() == [1.0, 10.0, 3.5]
+        # StatsAllReduce: one all-gather, summed on the host in rank order == the two all-reduces
+        assert np.array_equal(p["gi"], p["si"]) and np.array_equal(p["gf"], p["sf"])
     assert parts[0]["local_si"][O.ST_STEPS] * 2 == si[O.ST_STEPS]
     assert int(parts[1]["id0"]) == 500 + 48
 

@@ -17,16 +17,19 @@ pkg = importlib.import_module("2048_q-learning_amd")
 dev = torch.device("cuda:0")
 B = int(os.environ.get("INTERCEPT_BOARDS", str(1 << 20)))
 SS = (1, 2, 4, 8, 16, 32)
-env = pkg.BatchedGame2048Env(B, seed=0, device=dev)
-agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99, exploration_rate=0.95,
-                                  capacity_log2=30, seed=0, device=dev)
-agent.fused_rollout(env, 512, play_only=True)
-agent.ctr = env.ctr
-agent.fused_rollout(env, 32)
-torch.cuda.synchronize()
+def fresh():
+    """Mid-game boards and a young table (load 0.02 after the 32 learning steps): every variant starts equal."""
+    env = pkg.BatchedGame2048Env(B, seed=0, device=dev)
+    agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99, exploration_rate=0.95,
+                                      capacity_log2=30, seed=0, device=dev)
+    agent.fused_rollout(env, 512, play_only=True)
+    agent.ctr = env.ctr
+    agent.fused_rollout(env, 32)
+    torch.cuda.synchronize()
+    return env, agent
 
 
-def timed(S, reps, **kw):
+def timed(env, agent, S, reps, **kw):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for e0, e1 in ev:
         e0.record()
@@ -40,20 +43,18 @@ variants = [("play only (no table)", dict(play_only=True), {}),
             ("evaluation (probe only)", dict(learn=False), {}),
             ("learning, row cache", {}, {}),
             ("learning, no row cache", {}, {"row_cache_enabled": False}),
-            ("learning, row cache (again)", {}, {})]
+            ("learning, row cache (again)", {}, {}),
+            ("learning, no row cache (again)", {}, {"row_cache_enabled": False})]
 for name, kw, attrs in variants:
-    keep = {k: getattr(agent, k) for k in attrs}
+    env, agent = fresh()
     for k, v in attrs.items():
         setattr(agent, k, v)
     if name.startswith("play"):
-        keep_eps, agent.epsilon = agent.epsilon, 1.0
-    us = {S: timed(S, 7 if S <= 8 else 5, **kw) for S in SS}
-    if name.startswith("play"):
-        agent.epsilon = keep_eps
-        agent.ctr = env.ctr
-    for k, v in keep.items():
-        setattr(agent, k, v)
-    b, a = np.polyfit(np.array(SS[2:], dtype=float), np.array([us[S] for S in SS[2:]]), 1)
+        agent.epsilon = 1.0
+    us = {S: timed(env, agent, S, 5 if S <= 8 else 3, **kw) for S in SS}     # 183 steps: the table ends at load ~0.14
+    b, a = np.polyfit(np.array(SS, dtype=float), np.array([us[S] for S in SS]), 1)
     print(json.dumps({"variant": name, "boards": B, "launch_us": {str(S): round(v, 1) for S, v in us.items()},
-                      "fit_S>=4": {"intercept_us": round(float(a), 1), "per_step_us": round(float(b), 2)},
+                      "fit": {"intercept_us": round(float(a), 1), "per_step_us": round(float(b), 2)},
                       "load": round(agent.table_size() / float(1 << agent.capacity_log2), 4)}), flush=True)
+    del env, agent
+    torch.cuda.empty_cache()

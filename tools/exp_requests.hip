@@ -7,7 +7,12 @@
 //   hipcc -O3 --offload-arch=gfx950 -o tools/variants/exp_requests tools/exp_requests.hip
 //   tools/variants/exp_requests [cap_log2=28] [lanes_log2=20] [steps=64] [alloc_log2=cap_log2]
 //                               [only: run the combinations whose name contains this] [alloc mode:
-//                               0 hipMalloc, 1 fine-grained, 3 uncached (hipExtMallocWithFlags)]
+//                               0 hipMalloc, 1 fine-grained, 3 uncached (hipExtMallocWithFlags),
+//                               4 mapped from 2 MiB physical chunks (HIP virtual-memory API: what
+//                               q2048_table_alloc does)] [claim rate in 1/1024: how many of the lane-steps
+//                               that found their slot empty go on to claim it, default 1024]
+// Round 4 added: the 5x5 rollout's pattern (pub8: the winner of the claim publishes the second key
+// word with an 8-byte write-through store), a claim rate, and chunked tables.
 // Round 2 added: whole 64- / 128-byte lines written by one lane, a 1-bit-per-slot occupancy
 // bitmap (load + atomic OR as the claim), every cache-policy flavour of the probe load.
 #include <hip/hip_runtime.h>
@@ -47,11 +52,12 @@ __device__ __forceinline__ uint32_t grind(uint32_t a, uint32_t b, int work) {
 }
 
 enum { kLoad = 1, kCas = 2, kStore = 4, kCasAlways = 8, kStore16 = 16, kStore32 = 32, kCas2 = 64, kKey16 = 128,
-       kStore64 = 256, kStore128 = 512, kBmLoad = 1024, kBmOr = 2048, kBmOrAlways = 4096, kLoadIfSet = 8192 };
+       kStore64 = 256, kStore128 = 512, kBmLoad = 1024, kBmOr = 2048, kBmOrAlways = 4096, kLoadIfSet = 8192,
+       kPub8 = 16384, kLoad2 = 32768 };
 
 __global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, int64_t lanes, int steps,
                                                   int what, int work, uint32_t ctr0, uint32_t* sink,
-                                                  uint32_t* bitmap, int flavor) {
+                                                  uint32_t* bitmap, int flavor, uint32_t claim_rate) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= lanes) return;
   uint32_t acc = (uint32_t)i;
@@ -100,9 +106,17 @@ __global__ __launch_bounds__(256) void k_requests(Slot* table, uint64_t mask, in
       seen = (uint64_t)v.x | ((uint64_t)v.y << 32);
       acc ^= v.z ^ v2.x;
     }
-    if ((what & kCasAlways) || ((what & kCas) && seen == 0ull)) {
+    if ((what & kLoad2) && ((key >> 40) & 1023ull) >= claim_rate) {   // a hit: the row's second half (5x5: two loads)
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 v;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(reinterpret_cast<const char*>(&table[at]) + 16) : "memory");
+      acc ^= v.x;
+    }
+    if ((what & kCasAlways) || ((what & kCas) && seen == 0ull && ((key >> 40) & 1023ull) < claim_rate)) {
       const uint64_t r = atomicCAS(&table[at].key, 0ull, key);
       acc ^= (uint32_t)r;                       // the result is consumed (like the real claim)
+      if ((what & kPub8) && r == 0ull)          // 5x5: the winner publishes the second key word, write-through
+        __hip_atomic_store(&table[at].pad, key ^ 0x5555ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (what & kCas2) {                       // a second word of the same row (two-word keys)
         const uint64_t r2 = atomicCAS(&table[at].pad, 0ull, key ^ 0x5555ull);
         acc ^= (uint32_t)r2;
@@ -133,7 +147,8 @@ int main(int argc, char** argv) {
   const int steps = argc > 3 ? std::atoi(argv[3]) : 64;
   const int alloc_log2 = argc > 4 ? std::atoi(argv[4]) : cap_log2;   // allocate more than is used
   const char* only = argc > 5 ? argv[5] : nullptr;                   // run only combos whose name contains this
-  const int alloc_mode = argc > 6 ? std::atoi(argv[6]) : 0;          // 0 hipMalloc, 1 fine-grained, 3 uncached
+  const int alloc_mode = argc > 6 ? std::atoi(argv[6]) : 0;          // 0 hipMalloc, 1 fine-grained, 3 uncached, 4 chunks
+  const uint32_t claim_rate = argc > 7 ? (uint32_t)std::atoi(argv[7]) : 1024u;
   if (cap_log2 < 10 || cap_log2 > 32 || alloc_log2 < cap_log2 || alloc_log2 > 32 || lanes_log2 < 6 || lanes_log2 > 24 || steps < 1 || steps > 4096) {
     std::fprintf(stderr, "bad arguments\n");
     return 2;
@@ -144,7 +159,27 @@ int main(int argc, char** argv) {
   uint32_t* sink;
   uint32_t* bitmap;
   if (alloc_mode == 0) CK(hipMalloc(&table, (1ull << alloc_log2) * sizeof(Slot)));
-  else CK(hipExtMallocWithFlags(reinterpret_cast<void**>(&table), (1ull << alloc_log2) * sizeof(Slot), (unsigned)alloc_mode));
+  else if (alloc_mode == 4) {                  // 2 MiB physical chunks mapped into one reserved range
+    int dev = 0;
+    CK(hipGetDevice(&dev));
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    const size_t chunk = (size_t)2 << 20, bytes = (1ull << alloc_log2) * sizeof(Slot);
+    void* va = nullptr;
+    CK(hipMemAddressReserve(&va, bytes, chunk, nullptr, 0));
+    for (size_t k = 0; k < bytes / chunk; ++k) {
+      hipMemGenericAllocationHandle_t h;
+      CK(hipMemCreate(&h, chunk, &prop, 0));
+      CK(hipMemMap(static_cast<char*>(va) + k * chunk, chunk, 0, h, 0));
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(va, bytes, &acc, 1));
+    table = static_cast<Slot*>(va);
+  } else CK(hipExtMallocWithFlags(reinterpret_cast<void**>(&table), (1ull << alloc_log2) * sizeof(Slot), (unsigned)alloc_mode));
   CK(hipMalloc(&bitmap, cap / 8));
   CK(hipMalloc(&sink, 4));
   hipEvent_t e0, e1;
@@ -159,6 +194,9 @@ int main(int argc, char** argv) {
       {"load+cas+store32", kLoad | kCas | kStore32},
       {"load+cas+cas2+store", kLoad | kCas | kCas2 | kStore},
       {"load+cas+key16+store", kLoad | kCas | kKey16 | kStore},
+      {"load+cas+pub8+store", kLoad | kCas | kPub8 | kStore},
+      {"load+load2+cas+pub8+store", kLoad | kLoad2 | kCas | kPub8 | kStore},
+      {"load+load2+cas+store", kLoad | kLoad2 | kCas | kStore},
       {"store64", kStore64}, {"store128", kStore128}, {"load+store64", kLoad | kStore64},
       {"bmload", kBmLoad}, {"bmor(always)", kBmOrAlways}, {"bmload+bmor", kBmLoad | kBmOr},
       {"bmload+bmor+store32", kBmLoad | kBmOr | kStore32},
@@ -174,8 +212,8 @@ int main(int argc, char** argv) {
       {"load[sc0 sc1 nt]+cas+store", kLoad | kCas | kStore, 4}, {"load[sc1 nt]+cas+store", kLoad | kCas | kStore, 5},
       {"load[nt]+store", kLoad | kStore, 2}, {"load[sc0 sc1]+store", kLoad | kStore, 3},
       {"load32[sc0 sc1]+cas+store", kLoad | kCas | kStore, 8 | 3}};
-  std::printf("{\"alloc_mode\": %d, \"alloc_log2\": %d, \"cap_log2\": %d, \"lanes\": %lld, \"steps\": %d, \"unit\": \"us per step per 2^20 lanes\", \"rows\": [\n",
-              alloc_mode, alloc_log2, cap_log2, (long long)lanes, steps);
+  std::printf("{\"claim_rate_1024\": %u, \"alloc_mode\": %d, \"alloc_log2\": %d, \"cap_log2\": %d, \"lanes\": %lld, \"steps\": %d, \"unit\": \"us per step per 2^20 lanes\", \"rows\": [\n",
+              claim_rate, alloc_mode, alloc_log2, cap_log2, (long long)lanes, steps);
   bool first = true;
   for (auto& c : combos) {
     if (only != nullptr && std::strstr(c.name, only) == nullptr) continue;
@@ -184,13 +222,13 @@ int main(int argc, char** argv) {
       CK(hipMemsetAsync(bitmap, 0, cap / 8, 0));
       uint32_t ctr = 0;
       hipLaunchKernelGGL(k_requests, dim3(grid), dim3(256), 0, 0, table, cap - 1, lanes, steps, c.what,
-                         work, ctr, sink, bitmap, c.flavor);      // warm-up (fills steps*lanes keys)
+                         work, ctr, sink, bitmap, c.flavor, claim_rate);      // warm-up (fills steps*lanes keys)
       ctr += (uint32_t)steps;
       CK(hipEventRecord(e0, 0));
       const int reps = 3;
       for (int r = 0; r < reps; ++r) {
         hipLaunchKernelGGL(k_requests, dim3(grid), dim3(256), 0, 0, table, cap - 1, lanes, steps, c.what,
-                           work, ctr, sink, bitmap, c.flavor);
+                           work, ctr, sink, bitmap, c.flavor, claim_rate);
         ctr += (uint32_t)steps;
       }
       CK(hipEventRecord(e1, 0));
@@ -204,7 +242,7 @@ int main(int argc, char** argv) {
     }
   }
   std::printf("\n]}\n");
-  CK(hipFree(table));
+  if (alloc_mode != 4) CK(hipFree(table));     // (chunked: the process ends here)
   CK(hipFree(bitmap));
   CK(hipFree(sink));
   return 0;
