@@ -435,7 +435,8 @@ class BatchedQLearningAgent:
         opts = N.RolloutOpts(
             log=_ptr(log.records) if log is not None else None, log_capacity=log.capacity if log is not None else 0,
             log_count=_ptr(log.count) if log is not None else None, row_cache=_ptr(cache),
-            stats_mirror=self._mirror.data_ptr(), mirror_ticket=_ptr(self._mirror_ticket))
+            stats_mirror=self._mirror.data_ptr() if self.stats_i is not None and self.stats_f is not None else None,
+            mirror_ticket=_ptr(self._mirror_ticket))
         N.check(N.lib().q2048_fused_rollout_opts(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
             self.board_size, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,

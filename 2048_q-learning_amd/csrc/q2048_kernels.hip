@@ -18,6 +18,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -968,17 +969,41 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
 // run-time mode tests (kModeLearn: plain-store TD; kModeCas: Q2048_FLAG_TD_CAS; kModeEval:
 // Q2048_FLAG_NO_LEARN; play-only is an ENV bit).  Experiment builds select write modes at run time.
 constexpr int kModeLearn = 0, kModeCas = 1, kModeEval = 2;
-template <int N, int ENV, int MODE>
-__global__ __launch_bounds__(kBlock, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
+// Lanes per workgroup of the fused rollout: 512 for batches that fill the chip more than twice over at that
+// size (>= 786 432 boards), 256 below.  Nine alternating pairs of the driver's command at 1 Mi boards: 47.2 us
+// per step against 48.3 (8 of 9 pairs; 5x5: 64.4 against 66.4; profiles/r04_block512_*.txt) -- half as many
+// blocks end a launch with their statistics atomics on one cache line; at 65 536 boards 512-lane workgroups
+// would leave half of the CUs empty (8.0 against 5.6 us per step).  64- and 128-lane workgroups cost more than
+// they give at every size (profiles/r04_block_size_intercept.txt).
+constexpr int kFusedBlockBig = 512, kFusedBlockSmall = kBlock;
+constexpr int64_t kFusedBigBatch = 786432;
+#ifdef Q2048_EXPERIMENTS
+// Measurement builds only (tools/exp_timeline.py): when set (q2048_debug_timeline), every block of a fused
+// launch leaves four 100 MHz wall-clock stamps -- in, first step done, last step done, out -- and where it
+// ran (HW_ID: wave / SIMD / CU / SH / SE; XCC_ID) in g_timeline[blockIdx.x * 8 ..]: where in a launch the
+// chip is not full (ramp, rounds, drain), and whether some part of it is slower than the rest.
+__device__ unsigned long long* g_timeline;
+#define Q2048_STAMP(k) do { if (g_timeline != nullptr && threadIdx.x == 0) {                       \
+    g_timeline[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();                                     \
+    if ((k) == 0) {                                                                                \
+      g_timeline[(size_t)blockIdx.x * 8 + 4] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_REG_HW_ID */ \
+      g_timeline[(size_t)blockIdx.x * 8 + 5] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20); /* HW_REG_XCC_ID */ \
+    } } } while (0)
+#else
+#define Q2048_STAMP(k) do { } while (0)
+#endif
+template <int N, int ENV, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
     double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
     int64_t* stats_i, double* stats_f, uint32_t* status, q2048_episode* log, int64_t log_cap,
     u64* log_count, void* row_cache, u64* mirror, uint32_t* ticket) {
   RowCache<N>* const cache = static_cast<RowCache<N>*>(row_cache);
   __shared__ BlockStats bs;
-  __shared__ Stage<N> st;
+  __shared__ Stage<N, BLOCK / 64> st;
+  Q2048_STAMP(0);
   stats_clear(bs);
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   auto b = load_board(boards, i, B, st);
   if (i < B) {
     const uint64_t id = env_id0 + (uint64_t)i;
@@ -1095,7 +1120,9 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
       n_drop += wave_count(!updated && !play_only && !no_learn);
       n_done += wave_count(o.done != 0);
       reward_sum += (double)o.reward;
+      if (t == 0) Q2048_STAMP(1);
     }
+    Q2048_STAMP(2);
     if (pend && slot_s >= 0) flush_pending(&table[slot_s], q, pend);
     bool ins_last = false;  // the claim issued by the last step (its row belongs to the dict too)
     slot_s = claim_resolve(table, mask, key_s, claim, slot_s, ins_last);
@@ -1126,6 +1153,7 @@ __global__ __launch_bounds__(kBlock, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     stats_flush_acked(bs, stats_i, stats_f);
     stats_mirror(stats_i, stats_f, mirror, ticket);
   }
+  Q2048_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1881,14 +1909,18 @@ inline int check_table(const void* table, int cap_log2) {
     Q2048_LAUNCH_ENV_CASE(kernel, 3, n, B, stream, __VA_ARGS__)                                   \
   }
 // the fused rollout: ENV with the play-only bit, MODE = what the launch does with the table
+#define Q2048_LAUNCH_FUSED_ONE(NN, E, M, BLK, B, stream, ...)                                      \
+  hipLaunchKernelGGL((k_fused_rollout<NN, E, M, BLK>), dim3((unsigned)(((B) + (BLK) - 1) / (BLK))), dim3(BLK), 0, \
+                     (hipStream_t)(stream), __VA_ARGS__)
 #define Q2048_LAUNCH_FUSED_CASE(E, M, n, B, stream, ...)                                          \
   case (E) * 4 + (M):                                                                             \
-    if ((n) == 4)                                                                                 \
-      hipLaunchKernelGGL((k_fused_rollout<4, E, M>), dim3(grid_for(B)), dim3(kBlock), 0,          \
-                         (hipStream_t)(stream), __VA_ARGS__);                                     \
-    else                                                                                          \
-      hipLaunchKernelGGL((k_fused_rollout<5, E, M>), dim3(grid_for(B)), dim3(kBlock), 0,          \
-                         (hipStream_t)(stream), __VA_ARGS__);                                     \
+    if ((n) == 4) {                                                                               \
+      if ((B) >= kFusedBigBatch) Q2048_LAUNCH_FUSED_ONE(4, E, M, kFusedBlockBig, B, stream, __VA_ARGS__);     \
+      else Q2048_LAUNCH_FUSED_ONE(4, E, M, kFusedBlockSmall, B, stream, __VA_ARGS__);             \
+    } else {                                                                                      \
+      if ((B) >= kFusedBigBatch) Q2048_LAUNCH_FUSED_ONE(5, E, M, kFusedBlockBig, B, stream, __VA_ARGS__);     \
+      else Q2048_LAUNCH_FUSED_ONE(5, E, M, kFusedBlockSmall, B, stream, __VA_ARGS__);             \
+    }                                                                                             \
     break;
 #define Q2048_LAUNCH_FUSED_ENV(E, n, B, stream, ...)                                              \
   Q2048_LAUNCH_FUSED_CASE(E, kModeLearn, n, B, stream, __VA_ARGS__)                               \
@@ -1929,6 +1961,12 @@ inline int check_flags(uint32_t flags, uint32_t refused = 0u) {
 extern "C" {
 
 int q2048_abi_version(void) { return Q2048_ABI_VERSION; }
+
+#ifdef Q2048_EXPERIMENTS
+int q2048_debug_timeline(unsigned long long* stamps) {   // device uint64[blocks][8], or NULL to switch off
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &stamps, sizeof(stamps)) == hipSuccess ? Q2048_OK : Q2048_ERR_LAUNCH;
+}
+#endif
 
 int q2048_claim_timeouts(uint64_t* count_host) {
   if (count_host == nullptr) return Q2048_ERR_NULL;
@@ -2418,18 +2456,36 @@ int q2048_table_probe(q2048_slot* table, int cap_log2, int64_t lanes, int steps,
 // That is the rule the round-3 trap taught (below); it also means a table's address changes when it grows.
 namespace {
 struct Family { char* base; size_t bytes, chunk; int dev, cap0_log2, max_log2; };
-struct ChunkedTable { size_t bytes; int cap_log2; Family* fam; std::vector<hipMemGenericAllocationHandle_t> handles; };
+struct ChunkedTable { size_t bytes, chunk; int cap_log2; Family* fam; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_tables_mutex;
 std::map<void*, ChunkedTable> g_tables;
 std::vector<Family*> g_families;                         // kept for the life of the process (see release_chunks)
 
-size_t table_bytes(const Family& f, int cap_log2) {
-  const size_t want = sizeof(q2048_slot) << cap_log2;
-  return (want + f.chunk - 1) / f.chunk * f.chunk;
+// Chunk size of the table of capacity 2^cap_log2 in a family.  What hipMemCreate + hipMemMap + hipMemUnmap cost
+// PER CHUNK grows with the number of chunks a process holds (25 us each at 8192 chunks, 211 us each at 65 536:
+// mapping a 128 GiB table from 2 MiB chunks takes 13.8 s and un-mapping the 64 GiB one before it 2.7 s, while
+// moving its 10^9 rows takes 60 ms -- profiles/r04_growth_phases_2MiB_chunks.txt), so a table that GROWS is
+// mapped from at most kMaxChunks chunks: 2 MiB up to 16 GiB, then 4 / 8 / 16 MiB for 32 / 64 / 128 GiB.
+// (A family of one -- q2048_table_alloc, the fixed tables the bench runs on -- keeps the chunk size it asked
+// for: 2 MiB chunks are what makes an 8-32 GiB table fast, DESIGN.md 4 "table placement".)
+constexpr size_t kMaxChunks = 8192;
+size_t chunk_of(const Family& f, int cap_log2) {
+  size_t c = f.chunk;
+  if (f.max_log2 > f.cap0_log2)
+    while (((sizeof(q2048_slot) << cap_log2) + c - 1) / c > kMaxChunks) c <<= 1;
+  return c;
 }
-size_t family_offset(const Family& f, int cap_log2) {
+size_t table_bytes(const Family& f, int cap_log2) {
+  const size_t want = sizeof(q2048_slot) << cap_log2, c = chunk_of(f, cap_log2);
+  return (want + c - 1) / c * c;
+}
+size_t family_offset(const Family& f, int cap_log2) {   // every table starts at a multiple of its own chunk size
   size_t off = 0;
-  for (int k = f.cap0_log2; k < cap_log2; ++k) off += table_bytes(f, k);
+  for (int k = f.cap0_log2; k <= cap_log2; ++k) {
+    const size_t c = chunk_of(f, k < f.max_log2 + 1 ? k : f.max_log2);
+    off = (off + c - 1) / c * c;
+    if (k < cap_log2) off += table_bytes(f, k);
+  }
   return off;
 }
 // Freeing: every chunk is unmapped (one by one, as it was mapped) and its physical memory released;
@@ -2476,19 +2532,20 @@ int map_table(Family* f, int cap_log2, q2048_slot** out) {
   prop.location.type = hipMemLocationTypeDevice;
   prop.location.id = f->dev;
   ChunkedTable t;
+  t.chunk = chunk_of(*f, cap_log2);
   t.bytes = table_bytes(*f, cap_log2);
   t.cap_log2 = cap_log2;
   t.fam = f;
   char* va = f->base + family_offset(*f, cap_log2);
-  const size_t n = t.bytes / f->chunk;
+  const size_t n = t.bytes / t.chunk;
   t.handles.reserve(n);
   size_t mapped = 0;
   for (size_t k = 0; k < n; ++k) {
     hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, f->chunk, &prop, 0) != hipSuccess) { release_chunks(va, f->chunk, t.handles, mapped); return Q2048_ERR_ALLOC; }
+    if (hipMemCreate(&h, t.chunk, &prop, 0) != hipSuccess) { release_chunks(va, t.chunk, t.handles, mapped); return Q2048_ERR_ALLOC; }
     t.handles.push_back(h);
-    if (hipMemMap(va + k * f->chunk, f->chunk, 0, h, 0) != hipSuccess) {
-      release_chunks(va, f->chunk, t.handles, mapped);
+    if (hipMemMap(va + k * t.chunk, t.chunk, 0, h, 0) != hipSuccess) {
+      release_chunks(va, t.chunk, t.handles, mapped);
       return Q2048_ERR_ALLOC;
     }
     ++mapped;
@@ -2497,7 +2554,7 @@ int map_table(Family* f, int cap_log2, q2048_slot** out) {
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   if (hipMemSetAccess(va, t.bytes, &acc, 1) != hipSuccess || hipMemset(va, 0, t.bytes) != hipSuccess) {
-    release_chunks(va, f->chunk, t.handles, mapped);
+    release_chunks(va, t.chunk, t.handles, mapped);
     return Q2048_ERR_ALLOC;
   }
   // Silent row loss is the worst failure this library can have, and a table that does not read back as
@@ -2506,7 +2563,7 @@ int map_table(Family* f, int cap_log2, q2048_slot** out) {
   uint64_t rows = 0;
   int rc = count_rows_sync(reinterpret_cast<q2048_slot*>(va), cap_log2, &rows);
   if (rc == Q2048_OK && rows != 0) rc = Q2048_ERR_VERIFY;
-  if (rc != Q2048_OK) { release_chunks(va, f->chunk, t.handles, mapped); return rc; }
+  if (rc != Q2048_OK) { release_chunks(va, t.chunk, t.handles, mapped); return rc; }
   std::lock_guard<std::mutex> lock(g_tables_mutex);
   g_tables.emplace(va, std::move(t));
   *out = reinterpret_cast<q2048_slot*>(va);
@@ -2529,9 +2586,9 @@ int q2048_table_reserve(int cap_log2, int max_cap_log2, size_t chunk_bytes, q204
     return Q2048_ERR_ALLOC;
   Family* f = new Family{nullptr, 0, chunk_bytes ? chunk_bytes : ((size_t)2 << 20), dev, cap_log2, max_cap_log2};
   if (f->chunk % gran != 0) { delete f; return Q2048_ERR_SIZE; }
-  f->bytes = family_offset(*f, max_cap_log2 + 1);
+  f->bytes = family_offset(*f, max_cap_log2) + table_bytes(*f, max_cap_log2);
   void* va = nullptr;
-  if (hipMemAddressReserve(&va, f->bytes, f->chunk, nullptr, 0) != hipSuccess) { delete f; return Q2048_ERR_ALLOC; }
+  if (hipMemAddressReserve(&va, f->bytes, chunk_of(*f, max_cap_log2), nullptr, 0) != hipSuccess) { delete f; return Q2048_ERR_ALLOC; }
   f->base = static_cast<char*>(va);
   const int rc = map_table(f, cap_log2, table_out);
   if (rc != Q2048_OK) {
@@ -2563,8 +2620,17 @@ int q2048_table_grow(q2048_slot* table, int cap_log2, int new_cap_log2, int key_
   }
   if (new_cap_log2 <= cap_log2 || new_cap_log2 > f->max_log2) return Q2048_ERR_SIZE;
   DeviceGuard guard(f->dev);
+#ifdef Q2048_EXPERIMENTS   // Q2048_DEBUG_GROW=1: where a growth spends its time (stderr)
+  const bool dbg = getenv("Q2048_DEBUG_GROW") != nullptr;
+  auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+  double t_phase[5] = {now(), 0, 0, 0, 0};
+#define Q2048_GROW_MARK(k) do { if (dbg) t_phase[k] = now(); } while (0)
+#else
+#define Q2048_GROW_MARK(k) do { } while (0)
+#endif
   q2048_slot* bigger = nullptr;
   if (int e = map_table(f, new_cap_log2, &bigger)) return e;
+  Q2048_GROW_MARK(1);
   u64* counters = nullptr;
   int rc = hipMalloc(&counters, 16) == hipSuccess ? Q2048_OK : Q2048_ERR_ALLOC;
   unsigned long long host[2] = {0ull, 0ull};
@@ -2584,13 +2650,22 @@ int q2048_table_grow(q2048_slot* table, int cap_log2, int new_cap_log2, int key_
                          hipStreamSynchronize((hipStream_t)stream) != hipSuccess))
     rc = Q2048_ERR_LAUNCH;
   if (counters != nullptr) (void)hipFree(counters);
+  Q2048_GROW_MARK(2);
   // every row must have moved, and the new table must hold exactly those rows
   uint64_t rows = 0;
   if (rc == Q2048_OK) rc = count_rows_sync(bigger, new_cap_log2, &rows);
   if (rc == Q2048_OK && (host[1] != 0ull || rows != (uint64_t)host[0])) rc = Q2048_ERR_VERIFY;
   if (rc != Q2048_OK) { q2048_table_free(bigger); return rc; }   // the old table is intact and stays the caller's
   if (rows_moved != nullptr) *rows_moved = (int64_t)host[0];
+  Q2048_GROW_MARK(3);
   if (int e = q2048_table_free(table)) return e;
+  Q2048_GROW_MARK(4);
+#ifdef Q2048_EXPERIMENTS
+  if (dbg)
+    fprintf(stderr, "[q2048 debug] grow 2^%d -> 2^%d, %llu rows: map + zero + verify %.1f ms, move %.1f ms, count %.1f ms, "
+            "free the old table %.1f ms\n", cap_log2, new_cap_log2, host[0], t_phase[1] - t_phase[0], t_phase[2] - t_phase[1],
+            t_phase[3] - t_phase[2], t_phase[4] - t_phase[3]);
+#endif
   *table_out = bigger;
   return Q2048_OK;
 }
@@ -2617,7 +2692,7 @@ int q2048_table_free(q2048_slot* table) {
       const int m = atoi(mode);
       int bad_unmap = 0, bad_release = 0;
       for (size_t k = 0; k < t.handles.size(); ++k)
-        bad_unmap += hipMemUnmap(reinterpret_cast<char*>(table) + k * t.fam->chunk, t.fam->chunk) != hipSuccess;
+        bad_unmap += hipMemUnmap(reinterpret_cast<char*>(table) + k * t.chunk, t.chunk) != hipSuccess;
       for (auto& h : t.handles) bad_release += hipMemRelease(h) != hipSuccess;
       const hipError_t fr = hipMemAddressFree(t.fam->base, t.fam->bytes);
       const hipError_t sy = m >= 2 ? hipDeviceSynchronize() : hipSuccess;
@@ -2628,7 +2703,7 @@ int q2048_table_free(q2048_slot* table) {
     }
   }
 #endif
-  return release_chunks(table, t.fam->chunk, t.handles, t.handles.size()) ? Q2048_ERR_ALLOC : Q2048_OK;
+  return release_chunks(table, t.chunk, t.handles, t.handles.size()) ? Q2048_ERR_ALLOC : Q2048_OK;
 }
 
 int q2048_table_count(const q2048_slot* table, int cap_log2, int64_t* count, void* stream) {

@@ -1612,19 +1612,22 @@ def test_c_host_program_drives_the_abi(pkg, tmp_path):
                     "-o", exe, "-L", libdir, "-lq2048_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
                     f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}"], check=True)
     B, steps, seed, cap, eps = 5000, 70, 17, 21, 1.0
-    out = subprocess.run([exe, str(B), str(steps), str(seed), str(cap), str(eps)], check=True,
-                         capture_output=True, text=True).stdout
-    got = json.loads(out.strip().splitlines()[-1])
     env = pkg.BatchedGame2048Env(B, seed=seed, device=DEV)
     agent = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.99, exploration_rate=eps,
                                       capacity_log2=cap, seed=seed, device=DEV)
     agent.fused_rollout(env, steps)
     st = agent.stats()
-    for k in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "drops", "explored"):
-        assert got[k] == st[k], k
-    assert got["rows"] == agent.table_size() and got["status"] == 0
-    assert got["board0"] == env.boards[0].cpu().tolist()
-    assert np.isclose(got["return_sum"], st["return_sum"], rtol=1e-9)
+    # one launch through q2048_fused_rollout; then launches of 16 steps through q2048_fused_rollout_opts
+    # with a row cache and the statistics read from the host-side mirror
+    for per_launch in (0, 16):
+        out = subprocess.run([exe, str(B), str(steps), str(seed), str(cap), str(eps), str(per_launch)], check=True,
+                             capture_output=True, text=True).stdout
+        got = json.loads(out.strip().splitlines()[-1])
+        for k in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "drops", "explored"):
+            assert got[k] == st[k], (per_launch, k)
+        assert got["rows"] == agent.table_size() and got["status"] == 0
+        assert got["board0"] == env.boards[0].cpu().tolist()
+        assert np.isclose(got["return_sum"], st["return_sum"], rtol=1e-9)
 
 
 @pytest.mark.parametrize("n,B,steps,sort_bits", [(4, 3000, 80, 0), (5, 1500, 60, 0), (4, 60000, 24, 0),

@@ -43,9 +43,15 @@ variants = [("play only (no table)", dict(play_only=True), {}),
             ("evaluation (probe only)", dict(learn=False), {}),
             ("learning, row cache", {}, {}),
             ("learning, no row cache", {}, {"row_cache_enabled": False}),
+            ("learning, row cache, NO statistics (stats pointers NULL: no per-block flush, no mirror)", {},
+             {"stats_i": None, "stats_f": None}),
             ("learning, row cache (again)", {}, {}),
+            ("learning, row cache, NO statistics (again)", {}, {"stats_i": None, "stats_f": None}),
             ("learning, no row cache (again)", {}, {"row_cache_enabled": False})]
+ONLY = os.environ.get("INTERCEPT_ONLY")           # run the variants whose name starts with this
 for name, kw, attrs in variants:
+    if ONLY and not name.startswith(ONLY):
+        continue
     env, agent = fresh()
     for k, v in attrs.items():
         setattr(agent, k, v)

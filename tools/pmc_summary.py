@@ -32,7 +32,7 @@ for d in sorted(glob.glob(os.path.join(root, "pass*"))):
     for (k, c), per in sorted(acc.items()):
         if "k_fused_rollout" not in k and "k_table" not in k:
             continue
-        m = re.search(r"k_fused_rollout<\d, (\d)(?:, \d)?>", k)
+        m = re.search(r"k_fused_rollout<\d, (\d)", k)
         if m and int(m.group(1)) & 4:      # the learner-less instantiation (input synthesis): not the measured kernel
             continue
         vals = [per[i] for i in sorted(per)]
