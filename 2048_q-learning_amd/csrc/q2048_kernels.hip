@@ -2448,45 +2448,56 @@ int q2048_table_probe(q2048_slot* table, int cap_log2, int64_t lanes, int steps,
 // Table allocation from small physical chunks (HIP virtual-memory API).  The only entry points that
 // allocate; everything else works on caller-owned memory, wherever it came from.
 //
-// A FAMILY is one reserved address range with room for a table of every capacity from cap0 to max, one
-// after the other (offset of capacity 2^k = the sizes of the smaller ones before it: < 2 x the largest
-// in all).  q2048_table_reserve maps the first; q2048_table_grow maps the next capacity onto fresh
-// physical chunks, moves the rows over and releases the smaller table's chunks -- so every address of
-// the range is mapped at most ONCE in the life of the process, and the range itself is never freed.
-// That is the rule the round-3 trap taught (below); it also means a table's address changes when it grows.
+// A FAMILY is a table that may grow: q2048_table_reserve maps the first capacity, q2048_table_grow maps the
+// next one onto fresh physical chunks IN AN ADDRESS RANGE OF ITS OWN, moves the rows over and releases the
+// smaller table's chunks -- so every address is mapped at most ONCE in the life of the process and no range is
+// ever freed after it was mapped.  That is the rule the round-3 trap taught (below); it also means a table's
+// address changes when it grows.  (One reservation per table, starting exactly at the table: tables placed at
+// offsets inside one large reservation mapped, but hipMemSetAccess refused them -- invalid value -- whenever
+// their chunks were larger than 2 MiB and the reservation had not come back aligned to them.)
 namespace {
-struct Family { char* base; size_t bytes, chunk; int dev, cap0_log2, max_log2; };
+struct Family { size_t chunk; int dev, cap0_log2, max_log2; };
 struct ChunkedTable { size_t bytes, chunk; int cap_log2; Family* fam; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_tables_mutex;
 std::map<void*, ChunkedTable> g_tables;
-std::vector<Family*> g_families;                         // kept for the life of the process (see release_chunks)
+std::vector<Family*> g_families;                         // kept for the life of the process
 
 // Chunk size of the table of capacity 2^cap_log2 in a family.  What hipMemCreate + hipMemMap + hipMemUnmap cost
 // PER CHUNK grows with the number of chunks a process holds (25 us each at 8192 chunks, 211 us each at 65 536:
 // mapping a 128 GiB table from 2 MiB chunks takes 13.8 s and un-mapping the 64 GiB one before it 2.7 s, while
 // moving its 10^9 rows takes 60 ms -- profiles/r04_growth_phases_2MiB_chunks.txt), so a table that GROWS is
-// mapped from at most kMaxChunks chunks: 2 MiB up to 16 GiB, then 4 / 8 / 16 MiB for 32 / 64 / 128 GiB.
-// (A family of one -- q2048_table_alloc, the fixed tables the bench runs on -- keeps the chunk size it asked
-// for: 2 MiB chunks are what makes an 8-32 GiB table fast, DESIGN.md 4 "table placement".)
-constexpr size_t kMaxChunks = 8192;
+// mapped from at most kMaxChunks chunks: 2 MiB up to 16 GiB, 4 MiB for 32 GiB -- the sizes at which small
+// chunks are what makes a table fast (DESIGN.md 4 "table placement") -- and from 64 MiB chunks from 64 GiB on,
+// where how the memory was obtained no longer matters (a 128 GiB table is as fast from hipMalloc).
+// (A family of one -- q2048_table_alloc, the fixed tables the bench runs on -- keeps the chunk size it asked for.)
+constexpr size_t kMaxChunks = 8192, kBigTable = (size_t)64 << 30, kBigChunk = (size_t)64 << 20;
 size_t chunk_of(const Family& f, int cap_log2) {
   size_t c = f.chunk;
-  if (f.max_log2 > f.cap0_log2)
-    while (((sizeof(q2048_slot) << cap_log2) + c - 1) / c > kMaxChunks) c <<= 1;
+  if (f.max_log2 > f.cap0_log2) {
+    const size_t bytes = sizeof(q2048_slot) << cap_log2;
+    while ((bytes + c - 1) / c > kMaxChunks) c <<= 1;
+    if (bytes >= kBigTable && c < kBigChunk) c = kBigChunk;
+  }
   return c;
 }
-size_t table_bytes(const Family& f, int cap_log2) {
-  const size_t want = sizeof(q2048_slot) << cap_log2, c = chunk_of(f, cap_log2);
-  return (want + c - 1) / c * c;
-}
-size_t family_offset(const Family& f, int cap_log2) {   // every table starts at a multiple of its own chunk size
-  size_t off = 0;
-  for (int k = f.cap0_log2; k <= cap_log2; ++k) {
-    const size_t c = chunk_of(f, k < f.max_log2 + 1 ? k : f.max_log2);
-    off = (off + c - 1) / c * c;
-    if (k < cap_log2) off += table_bytes(f, k);
-  }
-  return off;
+// An address range of `bytes` that starts at a multiple of `align` and has never been mapped.  The
+// reservation's alignment argument is asked for and checked; when the runtime returns less (it honours the
+// granularity only, on this stack) a range one `align` larger is reserved to find room, given back UNMAPPED
+// (no translation of it ever existed: not the trap below) and reserved again at the aligned address inside it.
+void* reserve_aligned(size_t bytes, size_t align) {
+  void* va = nullptr;
+  if (hipMemAddressReserve(&va, bytes, align, nullptr, 0) != hipSuccess) return nullptr;
+  if (reinterpret_cast<uintptr_t>(va) % align == 0) return va;
+  if (hipMemAddressFree(va, bytes) != hipSuccess) return nullptr;
+  void* probe = nullptr;
+  if (hipMemAddressReserve(&probe, bytes + align, align, nullptr, 0) != hipSuccess) return nullptr;
+  const uintptr_t want = (reinterpret_cast<uintptr_t>(probe) + align - 1) / align * align;
+  if (hipMemAddressFree(probe, bytes + align) != hipSuccess) return nullptr;
+  va = nullptr;
+  if (hipMemAddressReserve(&va, bytes, align, reinterpret_cast<void*>(want), 0) != hipSuccess) return nullptr;
+  if (reinterpret_cast<uintptr_t>(va) % align == 0) return va;
+  (void)hipMemAddressFree(va, bytes);
+  return nullptr;
 }
 // Freeing: every chunk is unmapped (one by one, as it was mapped) and its physical memory released;
 // the ADDRESS RANGE is kept reserved for the life of the process and never handed out again.  On
@@ -2525,26 +2536,40 @@ int count_rows_sync(const q2048_slot* table, int cap_log2, uint64_t* rows) {
   *rows = (uint64_t)v;
   return rc;
 }
-// maps, zero-fills and verifies the table of capacity 2^cap_log2 of a family; registers it
-int map_table(Family* f, int cap_log2, q2048_slot** out) {
+// reserves, maps (from chunks of `chunk` bytes), zero-fills and verifies the table of capacity 2^cap_log2 of a
+// family; registers it
+int map_table_with(Family* f, int cap_log2, size_t chunk, q2048_slot** out) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
   prop.location.id = f->dev;
   ChunkedTable t;
-  t.chunk = chunk_of(*f, cap_log2);
-  t.bytes = table_bytes(*f, cap_log2);
   t.cap_log2 = cap_log2;
   t.fam = f;
-  char* va = f->base + family_offset(*f, cap_log2);
+  t.chunk = chunk;
+  t.bytes = ((sizeof(q2048_slot) << cap_log2) + chunk - 1) / chunk * chunk;
+  char* va = static_cast<char*>(reserve_aligned(t.bytes, chunk));
+  if (va == nullptr) return Q2048_ERR_ALLOC;
   const size_t n = t.bytes / t.chunk;
   t.handles.reserve(n);
   size_t mapped = 0;
-  for (size_t k = 0; k < n; ++k) {
+#ifdef Q2048_EXPERIMENTS
+#define Q2048_MAP_FAIL(what, e) fprintf(stderr, "[q2048 debug] map 2^%d slots, chunk %zu, chunk %zu of %zu: %s failed (%d)\n", cap_log2, t.chunk, k, n, what, (int)(e))
+#else
+#define Q2048_MAP_FAIL(what, e) do { } while (0)
+#endif
+  size_t k = 0;
+  for (; k < n; ++k) {
     hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, t.chunk, &prop, 0) != hipSuccess) { release_chunks(va, t.chunk, t.handles, mapped); return Q2048_ERR_ALLOC; }
+    if (hipError_t e = hipMemCreate(&h, t.chunk, &prop, 0)) {
+      Q2048_MAP_FAIL("hipMemCreate", e);
+      release_chunks(va, t.chunk, t.handles, mapped);
+      if (mapped == 0) (void)hipMemAddressFree(va, t.bytes);   // nothing was ever mapped here: the range can go back
+      return Q2048_ERR_ALLOC;
+    }
     t.handles.push_back(h);
-    if (hipMemMap(va + k * t.chunk, t.chunk, 0, h, 0) != hipSuccess) {
+    if (hipError_t e = hipMemMap(va + k * t.chunk, t.chunk, 0, h, 0)) {
+      Q2048_MAP_FAIL("hipMemMap", e);
       release_chunks(va, t.chunk, t.handles, mapped);
       return Q2048_ERR_ALLOC;
     }
@@ -2553,10 +2578,8 @@ int map_table(Family* f, int cap_log2, q2048_slot** out) {
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
-  if (hipMemSetAccess(va, t.bytes, &acc, 1) != hipSuccess || hipMemset(va, 0, t.bytes) != hipSuccess) {
-    release_chunks(va, t.chunk, t.handles, mapped);
-    return Q2048_ERR_ALLOC;
-  }
+  if (hipError_t e = hipMemSetAccess(va, t.bytes, &acc, 1)) { Q2048_MAP_FAIL("hipMemSetAccess", e); release_chunks(va, t.chunk, t.handles, mapped); return Q2048_ERR_ALLOC; }
+  if (hipError_t e = hipMemset(va, 0, t.bytes)) { Q2048_MAP_FAIL("hipMemset", e); release_chunks(va, t.chunk, t.handles, mapped); return Q2048_ERR_ALLOC; }
   // Silent row loss is the worst failure this library can have, and a table that does not read back as
   // zeros is how it would start (a slot that looks occupied swallows a key's probe sequence; stale
   // translations were seen once, above): one streaming count of the fresh table, ~5 ms per 32 GiB.
@@ -2568,6 +2591,13 @@ int map_table(Family* f, int cap_log2, q2048_slot** out) {
   g_tables.emplace(va, std::move(t));
   *out = reinterpret_cast<q2048_slot*>(va);
   return Q2048_OK;
+}
+// the table of a family: from at most kMaxChunks chunks if the stack will have it, else from the family's own
+int map_table(Family* f, int cap_log2, q2048_slot** out) {
+  const size_t chunk = chunk_of(*f, cap_log2);
+  int rc = map_table_with(f, cap_log2, chunk, out);
+  if (rc == Q2048_ERR_ALLOC && chunk != f->chunk) rc = map_table_with(f, cap_log2, f->chunk, out);
+  return rc;
 }
 }  // namespace
 
@@ -2584,18 +2614,10 @@ int q2048_table_reserve(int cap_log2, int max_cap_log2, size_t chunk_bytes, q204
   size_t gran = 0;
   if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0)
     return Q2048_ERR_ALLOC;
-  Family* f = new Family{nullptr, 0, chunk_bytes ? chunk_bytes : ((size_t)2 << 20), dev, cap_log2, max_cap_log2};
-  if (f->chunk % gran != 0) { delete f; return Q2048_ERR_SIZE; }
-  f->bytes = family_offset(*f, max_cap_log2) + table_bytes(*f, max_cap_log2);
-  void* va = nullptr;
-  if (hipMemAddressReserve(&va, f->bytes, chunk_of(*f, max_cap_log2), nullptr, 0) != hipSuccess) { delete f; return Q2048_ERR_ALLOC; }
-  f->base = static_cast<char*>(va);
+  Family* f = new Family{chunk_bytes ? chunk_bytes : ((size_t)2 << 20), dev, cap_log2, max_cap_log2};
+  if (f->chunk % gran != 0 || (f->chunk & (f->chunk - 1)) != 0) { delete f; return Q2048_ERR_SIZE; }
   const int rc = map_table(f, cap_log2, table_out);
-  if (rc != Q2048_OK) {
-    // nothing on the device has touched the range yet when the failure is an allocation failure: hand it
-    // back.  After a failed VERIFY it has been read: kept, like every range that was ever used.
-    if (rc != Q2048_ERR_VERIFY && hipMemAddressFree(va, f->bytes) == hipSuccess) { delete f; return rc; }
-  }
+  if (rc != Q2048_OK) { delete f; return rc; }
   std::lock_guard<std::mutex> lock(g_tables_mutex);
   g_families.push_back(f);
   return rc;
@@ -2694,7 +2716,7 @@ int q2048_table_free(q2048_slot* table) {
       for (size_t k = 0; k < t.handles.size(); ++k)
         bad_unmap += hipMemUnmap(reinterpret_cast<char*>(table) + k * t.chunk, t.chunk) != hipSuccess;
       for (auto& h : t.handles) bad_release += hipMemRelease(h) != hipSuccess;
-      const hipError_t fr = hipMemAddressFree(t.fam->base, t.fam->bytes);
+      const hipError_t fr = hipMemAddressFree(table, t.bytes);
       const hipError_t sy = m >= 2 ? hipDeviceSynchronize() : hipSuccess;
       if (m >= 3)
         fprintf(stderr, "[q2048 debug] free %p: %zu chunks, unmap errors %d, release errors %d, AddressFree %d, sync %d\n",

@@ -375,21 +375,24 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  * profiles/r03_requests/vmm_*_8GiB.txt; loads do not care) -- as fast as a table that spans 128 GiB.
  *
  * q2048_table_alloc reserves, creates, maps and zero-fills 2^cap_log2 slots (chunk_bytes = 0: 2 MiB;
- * else a multiple of the allocation granularity) on the current device, and VERIFIES the zero fill
+ * else a power of two that is a multiple of the allocation granularity) on the current device, and VERIFIES the zero fill
  * with one streaming count of the table before it returns (Q2048_ERR_VERIFY otherwise: a slot that
  * wrongly looks occupied is how rows would get lost silently).  Host-synchronous.
  *
  * A table that grows -- the reference's defaultdict (Agent/main.py:16) has no capacity:
- * q2048_table_reserve reserves the address range of every capacity from cap_log2 to max_cap_log2 at
- * once (less than 2 x the largest table; address space only) and maps the first;
+ * q2048_table_reserve maps a table of 2^cap_log2 slots that may grow up to 2^max_cap_log2;
  * q2048_table_grow(table, cap_log2, new_cap_log2, key_words, &bigger, &rows, stream) maps the table of
- * capacity 2^new_cap_log2 (cap_log2 < new_cap_log2 <= max_cap_log2) onto fresh chunks further along the
- * range, moves every row over in one streaming pass ordered on `stream` (the rows keep their values;
+ * capacity 2^new_cap_log2 (cap_log2 < new_cap_log2 <= max_cap_log2) onto fresh chunks in an address range
+ * of its own, moves every row over in one streaming pass ordered on `stream` (the rows keep their values;
  * their slots change: zero-fill any row cache), checks that the new table holds exactly the rows
  * the old one held (Q2048_ERR_VERIFY otherwise: the old table is then intact and still the caller's), and
  * releases the old table.  The table's ADDRESS changes: *table_out is the table from then on.
  * rows_moved (host int64, may be NULL) receives the number of rows.  Host-synchronous; while both
- * tables exist the device holds 1.5 x the new one.  The caller decides when: between launches, when
+ * tables exist the device holds 1.5 x the new one.  A table of a family that can grow is mapped from at
+ * most 8192 chunks (2 MiB up to 16 GiB, 4 MiB for 32 GiB, 64 MiB from 64 GiB on): what the virtual-memory
+ * calls cost per chunk grows with the number of chunks a process holds, and a 128 GiB table in 2 MiB chunks
+ * takes 14 s to map while moving its 10^9 rows takes 60 ms (profiles/r04_growth_phases_*.txt).  q2048_table_alloc
+ * keeps the chunk size it is asked for.  The caller decides when: between launches, when
  * rows created / capacity passes its load limit (the rollout's step slows from 46.7 to 66.3 us as the
  * load goes from 0.12 to 0.54, profiles/r03_load_curve.jsonl).
  *
