@@ -26,7 +26,8 @@ agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99,
 agent.fused_rollout(env, 512, play_only=True)
 agent.ctr = env.ctr
 agent.fused_rollout(env, 25)
-blocks = B // 256
+BLOCK = 512 if B >= 786432 else 256                 # the library's choice (csrc: kFusedBigBatch)
+blocks = B // BLOCK
 stamps = torch.zeros((blocks, 8), dtype=torch.int64, device=dev)
 for rep in range(3):
     stamps.zero_()
@@ -37,17 +38,22 @@ for rep in range(3):
     torch.cuda.synchronize()
     assert L.q2048_debug_timeline(None) == 0
     raw = stamps.cpu().numpy()
+    if not (raw[:, 0] > 0).all() or not (raw[:, 3] >= raw[:, 0]).all():   # a block that left no stamps: wrong grid assumed
+        raise SystemExit(f"{int((raw[:, 0] == 0).sum())} of {blocks} blocks left no stamps (block size {BLOCK}?)")
     hw, xcc = raw[:, 4], raw[:, 5] & 15
     cu, sh, se = (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7        # gfx9 HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
     t = raw[:, :4].astype(np.float64) / 100.0                    # us
     t -= t[:, 0].min()
     start, first, last, end = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
     total = end.max()
+    if total > 1e6:
+        raise SystemExit(f"a launch of {total:.0f} us? stamps are not from one launch")
     grid = np.arange(0.0, total, 1.0)
     inflight = np.array([((start <= x) & (end > x)).sum() for x in grid])
     full = inflight.max()
     order = np.argsort(start)
-    rounds = [order[:1536], order[1536:3072], order[3072:]]
+    resident = 1536 * 256 // BLOCK                   # 6 waves per SIMD
+    rounds = [order[:resident], order[resident:2 * resident], order[2 * resident:]]
     out = {"steps": S, "launch_us_by_events": round(e0.elapsed_time(e1) * 1e3, 1), "span_us_by_stamps": round(total, 1),
            "max_blocks_in_flight": int(full),
            "us_below_two_thirds_of_full": {"at_the_start": int((inflight[: len(grid) // 2] < full * 2 / 3).sum()),
