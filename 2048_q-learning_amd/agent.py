@@ -110,10 +110,10 @@ def _probe_us(table: torch.Tensor, capacity_log2: int, device: torch.device) -> 
 
 
 class _ChunkedTable:
-    """Owner of one q2048_table_reserve allocation (a table mapped from 2 MiB physical chunks, in an
-    address range with room for every capacity up to `max_capacity_log2`), handed to torch through
-    __cuda_array_interface__: the tensor keeps this object alive, and the memory goes back to the
-    device when the last reference is dropped."""
+    """Owner of one q2048_table_reserve allocation (a table mapped from small physical chunks that may
+    grow up to `max_capacity_log2`: `grow`), handed to torch through __cuda_array_interface__: the
+    tensor keeps this object alive, and the memory goes back to the device when the last reference is
+    dropped."""
 
     def __init__(self, capacity_log2: int, device: torch.device, chunk_bytes: int = 0,
                  max_capacity_log2: int | None = None, _adopt: int | None = None):
@@ -177,8 +177,8 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto", max_
       "plain"   torch.zeros (caching allocator -> hipMalloc): whatever the device yields
       n (int)   allocate up to n plain candidates at once, time q2048_table_probe on each (~2 ms,
                 contents untouched), keep the fastest, release the others
-    `max_capacity_log2` ("chunks" only): the table's address range has room for every capacity up to
-    that one (`BatchedQLearningAgent.grow_table`).
+    `max_capacity_log2` ("chunks" only): the table may grow up to that capacity
+    (`BatchedQLearningAgent.grow_table`).
     Returns (table, report); report["probe_us"] lists the probe's time on every candidate tried."""
     shape = (1 << capacity_log2, N.SIZEOF_SLOT)
     nbytes = N.SIZEOF_SLOT << capacity_log2
@@ -263,8 +263,8 @@ class BatchedQLearningAgent:
                     "auto": a table that GROWS, like the reference's defaultdict (Agent/main.py:16): it
                     starts at 2**initial_capacity_log2 slots (2^28 = 8 GiB) and, between launches, doubles
                     whenever the rows it holds pass `load_limit` (0.5) of its capacity
-                    (q2048_table_grow: the next capacity mapped further along one reserved address range,
-                    every row moved over by one streaming kernel, the smaller table released), up to the
+                    (q2048_table_grow: the next capacity mapped onto fresh chunks in an address range of its
+                    own, every row moved over by one streaming kernel, the smaller table released), up to the
                     largest capacity the device has room for next to its predecessor (2^32 slots =
                     128 GiB on an MI355X); `growths` lists what happened.  No update is dropped in any
                     run that fits the device.
@@ -521,17 +521,18 @@ class BatchedQLearningAgent:
 
     def grow_table(self, new_capacity_log2: int | None = None) -> int:
         """Doubles the table (or takes it to 2**new_capacity_log2 slots): q2048_table_grow maps the new
-        capacity further along the table's reserved address range, moves every row over with one streaming
+        capacity onto fresh chunks in an address range of its own, moves every row over with one streaming
         kernel and releases the smaller table -- after checking that the new table holds exactly the rows
-        the old one held.  Values are untouched, slots change: the row cache is emptied.  Only tables
-        made with capacity_log2="auto" can grow.  Returns the rows moved."""
+        the old one held.  Values are untouched, slots (and the table's address) change: the row cache is
+        emptied.  Host-synchronous: 0.3-0.8 s for 16-128 GiB, nearly all of it the virtual-memory calls
+        (DESIGN.md 3).  Only tables made with capacity_log2="auto" can grow.  Returns the rows moved."""
         owner = getattr(self.table, "_q2048_owner", None)
         if not self.growable or owner is None:
             raise RuntimeError('only a table made with capacity_log2="auto" can grow')
         new = self.capacity_log2 + 1 if new_capacity_log2 is None else int(new_capacity_log2)
         if not self.capacity_log2 < new <= self.max_capacity_log2:
             raise ValueError(f"cannot grow from 2^{self.capacity_log2} to 2^{new} slots "
-                             f"(this table's range ends at 2^{self.max_capacity_log2})")
+                             f"(this table's largest capacity is 2^{self.max_capacity_log2})")
         t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0[0].record()
         with torch.cuda.device(self.device):     # (raises with the old table intact and still self.table)

@@ -1890,7 +1890,7 @@ def test_chunked_tables_survive_reallocation(pkg):
 def test_table_grows_like_the_reference_defaultdict(pkg, n):
     """capacity_log2="auto": the reference's q_table is a defaultdict with no capacity
     (Agent/main.py:16); here the table starts small and DOUBLES between launches whenever half of it
-    is in use (q2048_table_grow: the next capacity mapped further along one reserved address range,
+    is in use (q2048_table_grow: the next capacity mapped onto fresh chunks in an address range of its own,
     rows moved by one streaming kernel, the smaller table released).  262 144 envs with private rows at
     eps = 0.2 (actions depend on Q), driven until the table has doubled at least twice: boards, aux,
     the key set and EVERY Q row equal, bit for bit, the same job on a table of fixed capacity;
