@@ -24,7 +24,10 @@ Protocol, per rank:
      over ranks): the MEDIAN region is the one reported.  Every region must
      finish episodes (`stats.episodes > 0`), or the reset / terminal-row path was not measured.
 Boards, aux records and the hash Q-table are resident in HBM throughout.  Rank 0 prints ONE
-JSON line.
+JSON line.  The launches go through q2048_fused_rollout_opts: every env's row passes from launch to
+launch through the row cache (`--no-row-cache`: each launch starts from a probe instead), and with one
+process the region's statistics are read from the host-side mirror the launch's last block writes
+(`--stats-by-copy`: a device-to-host copy queued behind the launches, as with several ranks).
 
 Extra objects on the line:
   roofline      HBM roofline of the dominant kernel (k_fused_rollout): algorithmic bytes per
