@@ -280,7 +280,9 @@ def _save(agent, path, world, rank):
     env = getattr(batched, "train_env", None)
     if env is not None:
         sd["env"] = env.state_dict()                                         # the games in progress
-    torch.save(sd, path if world == 1 else f"{path}.rank{rank}")
+    # (protocol 4: the rows of a long run are numpy arrays of more than 4 GiB -- 5.10^8 rows are 4 GB of keys
+    # and 8 GB of values -- which the default protocol of torch.save refuses)
+    torch.save(sd, path if world == 1 else f"{path}.rank{rank}", pickle_protocol=4)
 
 
 def main(argv=None):
