@@ -2466,18 +2466,18 @@ std::vector<Family*> g_families;                         // kept for the life of
 // PER CHUNK grows with the number of chunks a process holds (25 us each at 8192 chunks, 211 us each at 65 536:
 // mapping a 128 GiB table from 2 MiB chunks takes 13.8 s and un-mapping the 64 GiB one before it 2.7 s, while
 // moving its 10^9 rows takes 60 ms -- profiles/r04_growth_phases_2MiB_chunks.txt), so a table that GROWS is
-// mapped from at most kMaxChunks chunks: 2 MiB up to 16 GiB, 4 MiB for 32 GiB -- the sizes at which small
-// chunks are what makes a table fast (DESIGN.md 4 "table placement") -- and from 64 MiB chunks from 64 GiB on,
-// where how the memory was obtained no longer matters (a 128 GiB table is as fast from hipMalloc).
-// (A family of one -- q2048_table_alloc, the fixed tables the bench runs on -- keeps the chunk size it asked for.)
-constexpr size_t kMaxChunks = 8192, kBigTable = (size_t)64 << 30, kBigChunk = (size_t)64 << 20;
+// mapped from at most kMaxChunks chunks of at least its family's size and at most kBigChunk: 2 MiB up to 2 GiB,
+// 8 / 16 / 32 MiB for 8 / 16 / 32 GiB, 64 MiB from 64 GiB on (2048 chunks for 128 GiB: creating 128 MiB
+// physically contiguous chunks took longer than mapping twice as many).  The chunk size itself does not decide how fast a table takes
+// scattered writes: six fresh 16 and 32 GiB tables each from 2, 8, 32 and 64 MiB chunks span 44-56 us per 2^20
+// (load + CAS + store) with every size's range inside the others' (profiles/r04_requests/
+// chunk_size_six_draws.txt) -- which allocation a table got matters, not how it was cut.  (A family of one --
+// q2048_table_alloc, the fixed tables the bench runs on and probes four of -- keeps the chunk size it asked for.)
+constexpr size_t kMaxChunks = 1024, kBigChunk = (size_t)64 << 20;
 size_t chunk_of(const Family& f, int cap_log2) {
   size_t c = f.chunk;
-  if (f.max_log2 > f.cap0_log2) {
-    const size_t bytes = sizeof(q2048_slot) << cap_log2;
-    while ((bytes + c - 1) / c > kMaxChunks) c <<= 1;
-    if (bytes >= kBigTable && c < kBigChunk) c = kBigChunk;
-  }
+  if (f.max_log2 > f.cap0_log2)
+    while (((sizeof(q2048_slot) << cap_log2) + c - 1) / c > kMaxChunks && c < kBigChunk) c <<= 1;
   return c;
 }
 // An address range of `bytes` that starts at a multiple of `align` and has never been mapped.  The

@@ -389,7 +389,8 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  * releases the old table.  The table's ADDRESS changes: *table_out is the table from then on.
  * rows_moved (host int64, may be NULL) receives the number of rows.  Host-synchronous; while both
  * tables exist the device holds 1.5 x the new one.  A table of a family that can grow is mapped from at
- * most 8192 chunks (2 MiB up to 16 GiB, 4 MiB for 32 GiB, 64 MiB from 64 GiB on): what the virtual-memory
+ * most 1024 chunks of at most 64 MiB (2 MiB up to 2 GiB, 8 / 16 / 32 MiB for 8 / 16 / 32 GiB, 64 MiB
+ * beyond): what the virtual-memory
  * calls cost per chunk grows with the number of chunks a process holds, and a 128 GiB table in 2 MiB chunks
  * takes 14 s to map while moving its 10^9 rows takes 60 ms (profiles/r04_growth_phases_*.txt).  q2048_table_alloc
  * keeps the chunk size it is asked for.  The caller decides when: between launches, when

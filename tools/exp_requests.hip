@@ -10,7 +10,7 @@
 //                               0 hipMalloc, 1 fine-grained, 3 uncached (hipExtMallocWithFlags),
 //                               4 mapped from 2 MiB physical chunks (HIP virtual-memory API: what
 //                               q2048_table_alloc does)] [claim rate in 1/1024: how many of the lane-steps
-//                               that found their slot empty go on to claim it, default 1024]
+//                               that found their slot empty go on to claim it, default 1024] [MiB per chunk, mode 4]
 // Round 4 added: the 5x5 rollout's pattern (pub8: the winner of the claim publishes the second key
 // word with an 8-byte write-through store), a claim rate, and chunked tables.
 // Round 2 added: whole 64- / 128-byte lines written by one lane, a 1-bit-per-slot occupancy
@@ -149,6 +149,7 @@ int main(int argc, char** argv) {
   const char* only = argc > 5 ? argv[5] : nullptr;                   // run only combos whose name contains this
   const int alloc_mode = argc > 6 ? std::atoi(argv[6]) : 0;          // 0 hipMalloc, 1 fine-grained, 3 uncached, 4 chunks
   const uint32_t claim_rate = argc > 7 ? (uint32_t)std::atoi(argv[7]) : 1024u;
+  const size_t chunk_mib = argc > 8 ? (size_t)std::atoi(argv[8]) : 2;   // alloc mode 4: MiB per physical chunk
   if (cap_log2 < 10 || cap_log2 > 32 || alloc_log2 < cap_log2 || alloc_log2 > 32 || lanes_log2 < 6 || lanes_log2 > 24 || steps < 1 || steps > 4096) {
     std::fprintf(stderr, "bad arguments\n");
     return 2;
@@ -166,9 +167,10 @@ int main(int argc, char** argv) {
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = dev;
-    const size_t chunk = (size_t)2 << 20, bytes = (1ull << alloc_log2) * sizeof(Slot);
+    const size_t chunk = chunk_mib << 20, bytes = (1ull << alloc_log2) * sizeof(Slot);
     void* va = nullptr;
-    CK(hipMemAddressReserve(&va, bytes, chunk, nullptr, 0));
+    CK(hipMemAddressReserve(&va, bytes + chunk, chunk, nullptr, 0));
+    va = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(va) + chunk - 1) / chunk * chunk);   // (aligned by hand)
     for (size_t k = 0; k < bytes / chunk; ++k) {
       hipMemGenericAllocationHandle_t h;
       CK(hipMemCreate(&h, chunk, &prop, 0));
@@ -212,8 +214,8 @@ int main(int argc, char** argv) {
       {"load[sc0 sc1 nt]+cas+store", kLoad | kCas | kStore, 4}, {"load[sc1 nt]+cas+store", kLoad | kCas | kStore, 5},
       {"load[nt]+store", kLoad | kStore, 2}, {"load[sc0 sc1]+store", kLoad | kStore, 3},
       {"load32[sc0 sc1]+cas+store", kLoad | kCas | kStore, 8 | 3}};
-  std::printf("{\"claim_rate_1024\": %u, \"alloc_mode\": %d, \"alloc_log2\": %d, \"cap_log2\": %d, \"lanes\": %lld, \"steps\": %d, \"unit\": \"us per step per 2^20 lanes\", \"rows\": [\n",
-              claim_rate, alloc_mode, alloc_log2, cap_log2, (long long)lanes, steps);
+  std::printf("{\"chunk_mib\": %zu, \"claim_rate_1024\": %u, \"alloc_mode\": %d, \"alloc_log2\": %d, \"cap_log2\": %d, \"lanes\": %lld, \"steps\": %d, \"unit\": \"us per step per 2^20 lanes\", \"rows\": [\n",
+              chunk_mib, claim_rate, alloc_mode, alloc_log2, cap_log2, (long long)lanes, steps);
   bool first = true;
   for (auto& c : combos) {
     if (only != nullptr && std::strstr(c.name, only) == nullptr) continue;
