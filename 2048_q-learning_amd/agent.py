@@ -524,8 +524,8 @@ class BatchedQLearningAgent:
         capacity onto fresh chunks in an address range of its own, moves every row over with one streaming
         kernel and releases the smaller table -- after checking that the new table holds exactly the rows
         the old one held.  Values are untouched, slots (and the table's address) change: the row cache is
-        emptied.  Host-synchronous: 0.3-0.8 s for 16-128 GiB, nearly all of it the virtual-memory calls
-        (DESIGN.md 3).  Only tables made with capacity_log2="auto" can grow.  Returns the rows moved."""
+        emptied.  Host-synchronous: 50-180 ms up to 64 GiB, ~2 s for the step to 128 GiB, most of it the
+        virtual-memory calls.  Only tables made with capacity_log2="auto" can grow.  Returns the rows moved."""
         owner = getattr(self.table, "_q2048_owner", None)
         if not self.growable or owner is None:
             raise RuntimeError('only a table made with capacity_log2="auto" can grow')

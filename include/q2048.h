@@ -373,6 +373,9 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  * takes them 15-20 % faster than a hipMalloc of the same 8-32 GiB (load + compare-and-swap + store
  * per lane-step: 46.2 against 55.4 us per 2^20 on an 8 GiB table, 51.2 with 64 MiB chunks;
  * profiles/r03_requests/vmm_*_8GiB.txt; loads do not care) -- as fast as a table that spans 128 GiB.
+ * (Round 4, six fresh allocations per chunk size: 2, 8, 32 and 64 MiB chunks overlap completely,
+ * profiles/r04_requests/chunk_size_six_draws.txt -- the effect is mapped memory against hipMalloc and
+ * which allocation one got, not the chunk size.)
  *
  * q2048_table_alloc reserves, creates, maps and zero-fills 2^cap_log2 slots (chunk_bytes = 0: 2 MiB;
  * else a power of two that is a multiple of the allocation granularity) on the current device, and VERIFIES the zero fill
