@@ -442,11 +442,10 @@ def run_rank(args):
         # and BASELINE configs[4] (5x5 boards, 156 algorithmic bytes per env-step); each sized so
         # that its table ends below load 0.5
         comps = []
-        # 5x5 rows take two write requests to create (claim + second key word) and run 8 % faster on a
-        # table that spans 128 GiB than on a 32 GiB one (0.33 against 0.30 of its roofline on this
-        # command): its companion gets the large table when the device has the room
-        cap5 = max(cap_log2, pkg.auto_capacity_log2(B * max(learn_steps, 1), dev, max_log2=32, floor_log2=32,
-                                                    memory_fraction=0.6))
+        # (rounds 2-3 gave the 5x5 companion a 2^32-slot table: 0.34 against 0.30 on 32 GiB then.  Alternating
+        # runs on one box, round 4: 63.0 / 65.4 / 65.2 us per step on 2^30 slots in chunks against 65.0 / 64.5 /
+        # 64.9 on 2^32 -- profiles/r04_5x5_capacity_ab.txt -- so it runs on the main line's table size)
+        cap5 = cap_log2
         for name, c_eps, c_cap, c_n in (("capacity 2^28 (SURVEY 8(d))", args.eps, 28, args.board_size),
                                         ("epsilon 0.01 (argmax path)", 0.01, cap_log2, args.board_size),
                                         ("5x5 boards (BASELINE configs[4])", args.eps, cap5, 5)):
