@@ -308,7 +308,7 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
     placement_report = getattr(agent, "placement", None)
     del agent, synth, env
     torch.cuda.empty_cache()
-    return {"regions": regions, "table_rows": table_rows, "status": status,
+    return {"regions": regions, "table_rows": table_rows, "status": status, "mirrored": mirrored,
             "placement": placement_report, "prep_episodes_per_env": prep_episodes_per_env}
 
 
@@ -416,8 +416,8 @@ def run_rank(args):
                    "td_write": "compare-and-swap" if args.strict_td else "store (last writer wins)",
                    "table_placement": m["placement"], "experiment_bits": args.experiment_bits,
                    "row_cache": not args.no_row_cache,
-                   "region_statistics": "all-gather (one collective)" if world > 1 or args.stats_by_copy or args.agent != "hash"
-                                        else "host-side mirror written by the launch's last block",
+                   "region_statistics": "host-side mirror written by the launch's last block" if m["mirrored"] else (
+                       "all-gather (one collective)" if torch.distributed.is_initialized() else "copy to pinned host memory"),
                    "prep_steps": args.prep_steps, "repeats": args.repeats,
                    "timing": "median of `repeats` K-step regions after `prep_steps` of random play "
                              "and `warmup` learning steps",
