@@ -286,7 +286,8 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
             torch.cuda.synchronize(dev)
             si, sf = agent.mirrored_stats()
         else:
-            reducer.start(agent.stats_i, agent.stats_f)  # the path's only collective, on its own stream
+            reducer.start(agent.stats_i, agent.stats_f, snapshot=False)   # the path's only collective; nothing
+            # else touches the vectors before the region's closing wait: read in place, no clone, no side stream
             si, sf = reducer.wait()
             torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
