@@ -20,11 +20,12 @@ EXPERIMENTS_LIB_PATH = os.path.abspath(os.path.join(_PKG, "..", "tools", "varian
 SOURCES = ["q2048_kernels.hip"]
 DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc"]
 
-OK = 0
+OK, PENDING, ERR_BUSY = 0, 1, -10
+GROW_VERIFY_COUNT = 1
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
 FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
 FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY, FLAG_NO_LEARN = 8, 16, 32, 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
 ST_HIST0, NSTAT_I = 8, 32
 ST_HIST_BINS, ST_CAS_FALLBACK = 23, 31
@@ -155,6 +156,11 @@ _SIGNATURES = {
     "q2048_table_reserve": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "q2048_table_grow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_int64), C.c_void_p]),
+    "q2048_table_grow_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "q2048_table_grow_poll": (C.c_int, [C.c_void_p]),
+    "q2048_table_grow_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p]),
+    "q2048_table_grow_finish": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "q2048_table_grow_abort": (C.c_int, [C.c_void_p]),
     "q2048_table_free": (C.c_int, [C.c_void_p]),
     "q2048_table_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_void_p]),
     "q2048_table_count": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

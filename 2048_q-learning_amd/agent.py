@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 import weakref
 
 import numpy as np
@@ -145,14 +146,57 @@ class _ChunkedTable:
         return t
 
     def grow(self, new_capacity_log2: int, key_words: int, stream) -> "tuple[_ChunkedTable, int]":
-        """q2048_table_grow: the table of the next capacity, every row moved over, this one released
-        (its tensor must not be used again).  Returns (owner of the bigger table, rows moved)."""
+        """q2048_table_grow (host-synchronous): the table of the next capacity, every row moved over, this one
+        released (its tensor must not be used again).  Returns (owner of the bigger table, rows moved)."""
         ptr, moved = C.c_void_p(), C.c_int64(0)
         N.check(N.lib().q2048_table_grow(self.ptr, self.capacity_log2, int(new_capacity_log2), key_words,
                                          C.byref(ptr), C.byref(moved), stream), "q2048_table_grow")
         self._finalizer.detach()                # the library released this table's chunks itself
         return _ChunkedTable(new_capacity_log2, self.device, max_capacity_log2=self.max_capacity_log2,
                              _adopt=int(ptr.value)), int(moved.value)
+
+    def grow_begin(self, new_capacity_log2: int) -> "_Growth":
+        """q2048_table_grow_begin: the library's host thread starts mapping the bigger table; returns at once."""
+        return _Growth(self, int(new_capacity_log2))
+
+
+class _Growth:
+    """One q2048_table_grow_begin .. _commit .. _finish (or _abort): a growth off the caller's critical path.
+    Keeps the old table's owner alive until the library has released that table."""
+
+    def __init__(self, owner: _ChunkedTable, new_capacity_log2: int):
+        self.owner, self.new_capacity_log2 = owner, new_capacity_log2
+        self.handle, self.bigger, self.info = C.c_void_p(), None, {}
+        with torch.cuda.device(owner.device):
+            N.check(N.lib().q2048_table_grow_begin(owner.ptr, owner.capacity_log2, new_capacity_log2,
+                                                   C.byref(self.handle)), "q2048_table_grow_begin")
+
+    def ready(self) -> bool:
+        """True when the next call (commit, or finish after the commit) will not block."""
+        return N.lib().q2048_table_grow_poll(self.handle) != N.PENDING   # (a failure is "ready": the next call reports it)
+
+    def commit(self, key_words: int, stream, verify_count: bool = False) -> _ChunkedTable:
+        """q2048_table_grow_commit: the move is queued on `stream`; the bigger table is the table from here on."""
+        ptr = C.c_void_p()
+        with torch.cuda.device(self.owner.device):
+            N.check(N.lib().q2048_table_grow_commit(self.handle, key_words, N.GROW_VERIFY_COUNT if verify_count else 0,
+                                                    C.byref(ptr), stream), "q2048_table_grow_commit")
+        self.bigger = _ChunkedTable(self.new_capacity_log2, self.owner.device,
+                                    max_capacity_log2=self.owner.max_capacity_log2, _adopt=int(ptr.value))
+        return self.bigger
+
+    def finish(self) -> int:
+        """q2048_table_grow_finish: waits for the move, checks it, hands the old table to the library's host
+        thread for release.  Returns the rows moved (= the occupied slots of the old table)."""
+        moved = C.c_int64(0)
+        code = N.lib().q2048_table_grow_finish(self.handle, C.byref(moved))
+        if code == N.OK:
+            self.owner._finalizer.detach()      # the library releases the old table itself
+        N.check(code, "q2048_table_grow_finish")
+        return int(moved.value)
+
+    def abort(self) -> None:
+        N.check(N.lib().q2048_table_grow_abort(self.handle), "q2048_table_grow_abort")
 
 
 def _ranks_on_this_device() -> int:
@@ -161,7 +205,8 @@ def _ranks_on_this_device() -> int:
     return max(1, -(-world // max(torch.cuda.device_count(), 1)))
 
 
-def place_table(capacity_log2: int, device: torch.device, placement="auto", max_capacity_log2: int | None = None):
+def place_table(capacity_log2: int, device: torch.device, placement="auto", max_capacity_log2: int | None = None,
+                candidates: int | None = None):
     """Allocate the zeroed table where scattered writes run fast.
 
     How a multi-GiB table's memory was obtained moves the scattered store / atomic rate of the
@@ -178,14 +223,17 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto", max_
       n (int)   allocate up to n plain candidates at once, time q2048_table_probe on each (~2 ms,
                 contents untouched), keep the fastest, release the others
     `max_capacity_log2` ("chunks" only): the table may grow up to that capacity
-    (`BatchedQLearningAgent.grow_table`).
+    (`BatchedQLearningAgent.grow_table`).  `candidates` ("chunks" only): how many tables to map and probe at most
+    (default: up to four on a device of one rank, ONE in a multi-rank job -- eight ranks each mapping 4 x 32 GiB at
+    start-up are 8 x 1.2 s of driver calls for a <= 7 % effect -- and one for a table that will grow: it is replaced
+    at its first growth anyway, and memory released moments before is what makes the next mapping slow).
     Returns (table, report); report["probe_us"] lists the probe's time on every candidate tried."""
     shape = (1 << capacity_log2, N.SIZEOF_SLOT)
     nbytes = N.SIZEOF_SLOT << capacity_log2
     if placement == "auto":
         if (1 << 30) <= nbytes <= (64 << 30):
             try:
-                return place_table(capacity_log2, device, "chunks", max_capacity_log2)
+                return place_table(capacity_log2, device, "chunks", max_capacity_log2, candidates)
             except (N.NativeError, RuntimeError) as exc:      # no virtual-memory API on this stack, or no room:
                 table = torch.zeros(shape, dtype=torch.uint8, device=device)   # the slower kind of table
                 return table, {"mode": "plain", "chunks_failed": str(exc)}
@@ -198,7 +246,10 @@ def place_table(capacity_log2: int, device: torch.device, placement="auto", max_
         # 49-51 us on 2^28 and 2^30 slots); each candidate costs its mapping + zero-fill (~0.3 s for 32 GiB)
         # (ranks that share one device -- rehearsals of a multi-GPU job on a one-GPU box -- share its free memory)
         free, _ = torch.cuda.mem_get_info(device)
-        tries = int(max(1, min(4, (0.5 * free / _ranks_on_this_device()) // nbytes)))
+        if candidates is None:
+            world = int(os.environ.get("WORLD_SIZE", "1"))
+            candidates = 1 if (world > 1 or (max_capacity_log2 or capacity_log2) > capacity_log2) else 4
+        tries = int(max(1, min(int(candidates), (0.5 * free / _ranks_on_this_device()) // nbytes)))
         tables, times = [], []
         for _ in range(tries):
             try:
@@ -260,14 +311,21 @@ class BatchedQLearningAgent:
     capacity_log2   an int: the table has 2**capacity_log2 slots of 32 B, fixed at construction; when an
                     update finds no free slot within the probe limit it is dropped and counted
                     (stats['drops'], status TABLE_FULL) -- never an exception.
-                    "auto": a table that GROWS, like the reference's defaultdict (Agent/main.py:16): it
-                    starts at 2**initial_capacity_log2 slots (2^28 = 8 GiB) and, between launches, doubles
-                    whenever the rows it holds pass `load_limit` (0.5) of its capacity
-                    (q2048_table_grow: the next capacity mapped onto fresh chunks in an address range of its
-                    own, every row moved over by one streaming kernel, the smaller table released), up to the
-                    largest capacity the device has room for next to its predecessor (2^32 slots =
-                    128 GiB on an MI355X); `growths` lists what happened.  No update is dropped in any
-                    run that fits the device.
+                    "auto": a table that GROWS, like the reference's defaultdict (Agent/main.py:16), without
+                    stopping the loop.  It starts at 2**initial_capacity_log2 slots ("auto": 2^30 = 32 GiB when
+                    that is at most an eighth of the free device memory, else the largest power of two that is,
+                    at least 2^20) and, between launches, grows by a factor 2**growth_step_log2 (4) whenever the
+                    rows it holds pass `load_limit` (0.5) of its capacity: the next table is mapped by the
+                    library's host thread while rollouts go on (`prefetch_growth`: started as soon as the current
+                    table is in place; else at half the limit), the move of the rows is queued on the stream
+                    between two launches, the check (rows moved == rows the kernels created) and the release of
+                    the old table happen later, off the critical path (q2048_table_grow_begin / _commit /
+                    _finish).  Up to the largest capacity the device has room for next to its predecessor
+                    (2^32 slots = 128 GiB on an MI355X); `growths` lists what happened.  No update is dropped in
+                    any run that fits the device.  If the device has no virtual-memory API or no room for the
+                    first table the agent falls back to ONE fixed plain table (a warning says so).
+                    `async_growth=False`: the host-synchronous q2048_table_grow of round 4 instead (same result,
+                    bit for bit: tested).
     independent     every env owns private rows (keys salted with its global id): B independent
                     learners in one table, exactly B reference agents side by side.
     placement       how the table is allocated (`place_table`): "auto", "chunks", "plain" or a count
@@ -284,7 +342,9 @@ class BatchedQLearningAgent:
                  exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 24,
                  device="cuda", seed: int = 0, env_id0: int = 0, independent: bool = False,
                  strict_td: bool = False, board_size: int = 4, placement="auto", row_cache: bool = True,
-                 initial_capacity_log2: int = 28, max_capacity_log2: int | None = None, load_limit: float = 0.5):
+                 initial_capacity_log2="auto", max_capacity_log2: int | None = None, load_limit: float = 0.5,
+                 growth_step_log2: int = 2, prefetch_growth: bool = True, async_growth: bool = True,
+                 verify_growth: bool = False):
         self.device = _require_gpu(device)
         if action_space != 4:
             raise ValueError("the 2048 action space has 4 actions")
@@ -293,13 +353,19 @@ class BatchedQLearningAgent:
         self.board_size, self.cells = int(board_size), int(board_size) ** 2
         self.growable = capacity_log2 == "auto"
         self.load_limit, self.growths = float(load_limit), []
+        self.growth_step_log2, self.prefetch_growth = max(1, int(growth_step_log2)), bool(prefetch_growth)
+        self.async_growth, self.verify_growth = bool(async_growth), bool(verify_growth)
+        self._growth = self._retiring = None      # a growth being prepared / one committed and not yet finished
         if self.growable:
             if not 0.05 <= self.load_limit <= 0.9:
                 raise ValueError("load_limit must be in [0.05, 0.9]")
-            capacity_log2 = int(initial_capacity_log2)
-            # the largest table that fits next to its predecessor (1.5 x its size while rows move over)
             free, _ = torch.cuda.mem_get_info(self.device)
-            fit = int(np.floor(np.log2(max(0.9 * free / _ranks_on_this_device() / (1.5 * N.SIZEOF_SLOT), 16.0))))
+            share = free / _ranks_on_this_device()
+            if initial_capacity_log2 == "auto":   # an eighth of the free memory, at most 2^30 slots (32 GiB)
+                initial_capacity_log2 = min(30, max(20, int(np.floor(np.log2(max(share / 8 / N.SIZEOF_SLOT, 2.0))))))
+            capacity_log2 = int(initial_capacity_log2)
+            # the largest table that fits next to its predecessor while the rows move over
+            fit = int(np.floor(np.log2(max(0.9 * share / (1.5 * N.SIZEOF_SLOT), 16.0))))
             self.max_capacity_log2 = max(capacity_log2, min(int(max_capacity_log2 or 34), fit, 40))
             placement = "chunks"                      # growth is a property of the chunk allocator
         else:
@@ -316,13 +382,29 @@ class BatchedQLearningAgent:
         self.flags = (N.FLAG_INDEPENDENT if independent else 0) | (N.FLAG_TD_CAS if strict_td else 0)
         self.experiment_bits = 0  # unstable tuning bits OR-ed into fused_rollout's flags
         self.ctr = 0  # choose_action calls so far = counter word of the step draws
-        self.table, self.placement = place_table(self.capacity_log2, self.device, placement,
-                                                 self.max_capacity_log2 if self.growable else None)
-        # row bookkeeping (growth, `verify_table`): rows known to be in the table at the last count, the
-        # upper bound on rows created since (two per env-step: a state's own row and its successor's), the
-        # cumulative insert counter (statistics resets fold into it) and its value at the last count
-        self._rows_known, self._rows_maybe = 0, 0
-        self._inserts_folded, self._inserts_at_count = 0, 0
+        try:
+            self.table, self.placement = place_table(self.capacity_log2, self.device, placement,
+                                                     self.max_capacity_log2 if self.growable else None)
+        except (N.NativeError, RuntimeError) as exc:
+            if not self.growable:
+                raise
+            # no virtual-memory API on this stack, or no room: one fixed table, as large as a quarter of the
+            # free memory allows (at most 2^30 slots), from the ordinary allocator -- and say so
+            self.growable = False
+            self.capacity_log2 = self.max_capacity_log2 = auto_capacity_log2(0, self.device, floor_log2=30)
+            warnings.warn(f'capacity_log2="auto": the growing table could not be mapped ({exc}); using a fixed '
+                          f"table of 2^{self.capacity_log2} slots instead (updates beyond it are dropped and counted)")
+            self.table, self.placement = place_table(self.capacity_log2, self.device, "plain")
+            self.placement["growable_failed"] = str(exc)
+        # row bookkeeping (growth, `verify_table`): the rows in the table are known EXACTLY at any stream point --
+        # the rows counted at the last count / import (`_rows_base`) + the rows the kernels created since
+        # (Q2048_ST_INSERTS, cumulative over statistics resets: `_inserts_folded`) -- at the price of one 8-byte
+        # synchronising read, which `_room_for` pays only when an upper bound kept on the host (two new rows per
+        # env-step launched since the last read) says a threshold may have been passed
+        self._rows_base, self._inserts_at_base = 0, 0
+        self._inserts_folded, self._inserts_seen, self._steps_unseen = 0, 0, 0
+        self._steps_at_read, self._steps_launched, self._row_rate = 0, 0, 1.0
+        self._warned_full = False
         self.stats_i, self.stats_f = new_stats_vectors(self.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.q_table = _QTableView(self)
@@ -334,6 +416,8 @@ class BatchedQLearningAgent:
         self._mirror_np = self._mirror.numpy()
         self._mirror_ticket = torch.zeros(2, dtype=torch.int32, device=self.device)
         self._mirror_launches = 0
+        if self.growable and self.async_growth and self.prefetch_growth:
+            self._begin_growth()                  # the next table is being mapped while the run sets itself up
 
     def _cache(self, B: int):
         """The row cache for a batch of B envs (device pointer or None)."""
@@ -491,41 +575,136 @@ class BatchedQLearningAgent:
         self.ctr += int(steps)
 
     # -- a table that grows (capacity_log2="auto") ------------------------------------------------
-    def _room_for(self, env_steps: int) -> None:
-        """Called before anything that may create rows: `env_steps` env-steps are about to run, each
-        of which creates at most two rows (a state's own and its successor's, Agent/main.py:41-43).
-        Cheap while the bound says the table cannot pass its load limit; otherwise the rows are
-        counted (one streaming pass, synchronising) and the table doubles until the expected rows of
-        the call -- one per env-step -- fit under the limit."""
-        self._rows_maybe += 2 * int(env_steps)
-        if not self.growable:
-            return
-        limit = self.load_limit * (1 << self.capacity_log2)
-        if self._rows_known + self._rows_maybe <= limit:
-            return
-        self._count_rows()
-        self._rows_maybe = 2 * int(env_steps)
-        while (self._rows_known + int(env_steps) > self.load_limit * (1 << self.capacity_log2)
-               and self.capacity_log2 < self.max_capacity_log2):
-            self.grow_table()
-
     def _cumulative_inserts(self) -> int:
         return self._inserts_folded + int(self.stats_i[N.ST_INSERTS].item())
 
-    def _count_rows(self) -> int:
-        """Occupied slots, counted on the device (synchronising); the new base of the row bookkeeping."""
-        self._rows_known = self.table_size()
-        self._inserts_at_count = self._cumulative_inserts()
-        self._rows_maybe = 0
-        return self._rows_known
+    def _rows_exact(self) -> int:
+        """Rows in the table at this point of the stream: one synchronising 8-byte read of the kernels' own
+        counter (no scan).  Also refreshes the rows-per-env-step estimate the growth policy plans with."""
+        seen = self._cumulative_inserts()
+        steps = self._steps_launched - self._steps_at_read
+        if steps > 0:
+            self._row_rate = min(2.0, max(0.02, 1.25 * (seen - self._inserts_seen) / steps))
+        self._inserts_seen, self._steps_at_read, self._steps_unseen = seen, self._steps_launched, 0
+        return self._rows_base + seen - self._inserts_at_base
 
-    def grow_table(self, new_capacity_log2: int | None = None) -> int:
-        """Doubles the table (or takes it to 2**new_capacity_log2 slots): q2048_table_grow maps the new
-        capacity onto fresh chunks in an address range of its own, moves every row over with one streaming
-        kernel and releases the smaller table -- after checking that the new table holds exactly the rows
-        the old one held.  Values are untouched, slots (and the table's address) change: the row cache is
-        emptied.  Host-synchronous: 50-180 ms up to 64 GiB, ~2 s for the step to 128 GiB, most of it the
-        virtual-memory calls.  Only tables made with capacity_log2="auto" can grow.  Returns the rows moved."""
+    def _rebase_rows(self, rows: int) -> None:
+        """`rows` rows are in the table now (a count, an import): the new base of the row bookkeeping."""
+        self._rows_base = int(rows)
+        self._inserts_at_base = self._inserts_seen = self._cumulative_inserts()
+        self._steps_at_read, self._steps_unseen = self._steps_launched, 0
+
+    def _room_for(self, env_steps: int) -> None:
+        """Called before anything that may create rows: `env_steps` env-steps are about to be queued, each of
+        which creates at most two rows (a state's own and its successor's, Agent/main.py:41-43).  Costs nothing
+        while the host-side bound says no threshold can have been passed.  Otherwise the exact row count is read
+        (8 bytes, synchronising) and
+          - the next table starts being mapped (`prefetch_growth`: already at construction / after each growth;
+            else when the rows expected after this call pass half the load limit),
+          - the growth is committed -- the move queued between this launch and the previous one -- when the rows
+            expected after this call (measured rows per env-step x 1.25) pass `load_limit` AND the next table is
+            ready; when it is not ready yet the rollouts go on on the old table until the worst case (two rows
+            per env-step) would pass load_limit + 0.25 (at most 0.85), and only then wait for it.
+        A table at its largest capacity warns once when it passes the limit."""
+        env_steps = int(env_steps)
+        self._steps_launched += env_steps
+        if not self.growable:
+            return
+        if self._retiring is not None and self._retiring.ready():
+            self._finish_retiring()
+        cap = 1 << self.capacity_log2
+        soft = self.load_limit * cap
+        at_max = self.capacity_log2 >= self.max_capacity_log2
+        trigger = soft if (self._growth is not None or at_max) else 0.5 * soft
+        bound = self._rows_base + self._inserts_seen - self._inserts_at_base + 2 * (self._steps_unseen + env_steps)
+        if bound <= trigger:
+            self._steps_unseen += env_steps
+            return
+        self._steps_launched -= env_steps                # (the read below must not count steps not yet queued)
+        rows = self._rows_exact()
+        self._steps_launched += env_steps
+        self._steps_unseen = env_steps
+        while True:
+            cap = 1 << self.capacity_log2
+            soft, hard = self.load_limit * cap, min(0.85, self.load_limit + 0.25) * cap
+            expect, worst = rows + self._row_rate * env_steps, rows + 2 * env_steps
+            if self.capacity_log2 >= self.max_capacity_log2:
+                if rows > soft and not self._warned_full:
+                    self._warned_full = True
+                    warnings.warn(f"the Q-table is at its largest capacity (2^{self.capacity_log2} slots) and holds "
+                                  f"{rows} rows (load {rows / cap:.2f} > {self.load_limit}): lookups slow down, and "
+                                  "updates that find no slot within the probe limit are dropped and counted")
+                return
+            if not self.async_growth:
+                if expect > soft or worst > hard:
+                    self.grow_table(min(self.capacity_log2 + self.growth_step_log2, self.max_capacity_log2), _rows=rows)
+                    continue
+                return
+            if self._growth is None and (self.prefetch_growth or expect > 0.5 * soft):
+                self._begin_growth()
+            if self._growth is not None and (worst > hard or (expect > soft and self._growth.ready())):
+                self._commit_growth(rows)
+                continue                                  # (a launch larger than the new table's room: again)
+            return
+
+    def _begin_growth(self) -> None:
+        owner = getattr(self.table, "_q2048_owner", None)
+        if owner is None or self.capacity_log2 >= self.max_capacity_log2:
+            return
+        new = min(self.capacity_log2 + self.growth_step_log2, self.max_capacity_log2)
+        self._growth = owner.grow_begin(new)
+        self._growth.info = {"begun_at_step": self.ctr}
+
+    def _commit_growth(self, rows: int) -> None:
+        """Queues the move of the `rows` rows (exact: read at this stream point) into the prepared table."""
+        import time
+        if self._retiring is not None:                    # the family's counters are free again after its check
+            self._finish_retiring()
+        g, t0 = self._growth, time.perf_counter()
+        ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev[0].record()
+        with torch.cuda.device(self.device):              # (raises with the old table intact and still self.table)
+            try:
+                bigger = g.commit(1 if self.board_size == 4 else 2, _stream(self.device), self.verify_growth)
+            except N.NativeError:
+                self._growth = None
+                raise
+        ev[1].record()
+        self.table = bigger.tensor(self.device)           # every launch from here on takes the new table
+        self.table._q2048_owner = bigger
+        g.info.update({"from_log2": self.capacity_log2, "to_log2": g.new_capacity_log2, "expected_rows": int(rows),
+                       "at_step": self.ctr, "host_ms": round((time.perf_counter() - t0) * 1e3, 3), "events": ev})
+        self.capacity_log2 = g.new_capacity_log2
+        self.invalidate_row_cache()                       # slots changed
+        self._growth, self._retiring = None, g
+        if self.prefetch_growth:
+            self._begin_growth()
+
+    def _finish_retiring(self) -> None:
+        """The committed growth's move is over (or is waited for): rows moved == rows the kernels created, else
+        RuntimeError; the old table goes back to the device from the library's host thread."""
+        g, self._retiring = self._retiring, None
+        moved = g.finish()
+        ev = g.info.pop("events")
+        g.info.update({"rows": moved, "ms": round(ev[0].elapsed_time(ev[1]), 3)})
+        self.growths.append(g.info)
+        if moved != g.info["expected_rows"]:
+            raise RuntimeError(f"Q-table self-check failed at the growth 2^{g.info['from_log2']} -> "
+                               f"2^{g.info['to_log2']}: {moved} occupied slots moved, {g.info['expected_rows']} rows "
+                               "created according to the kernels' counters")
+
+    def finish_growth(self) -> None:
+        """Waits for a committed growth's move and runs its check (the end of a run, `verify_table`, tests)."""
+        if self._retiring is not None:
+            self._finish_retiring()
+
+    def grow_table(self, new_capacity_log2: int | None = None, _rows: int | None = None) -> int:
+        """Host-synchronous growth (q2048_table_grow): doubles the table (or takes it to 2**new_capacity_log2
+        slots) -- the new capacity mapped onto fresh chunks in an address range of its own, every row moved over
+        with one streaming kernel, the new table counted, the smaller one released.  Values are untouched, slots
+        (and the table's address) change: the row cache is emptied.  30-180 ms up to 128 GiB on memory that has
+        been free for a while.  Only tables made with capacity_log2="auto" can grow.  Returns the
+        rows moved.  (`_room_for` uses the asynchronous begin / commit / finish form instead.)"""
         owner = getattr(self.table, "_q2048_owner", None)
         if not self.growable or owner is None:
             raise RuntimeError('only a table made with capacity_log2="auto" can grow')
@@ -533,6 +712,11 @@ class BatchedQLearningAgent:
         if not self.capacity_log2 < new <= self.max_capacity_log2:
             raise ValueError(f"cannot grow from 2^{self.capacity_log2} to 2^{new} slots "
                              f"(this table's largest capacity is 2^{self.max_capacity_log2})")
+        self.finish_growth()
+        if self._growth is not None:                      # a prepared table of another size: give it back
+            g, self._growth = self._growth, None
+            g.abort()
+        expected = self._rows_exact() if _rows is None else int(_rows)
         t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0[0].record()
         with torch.cuda.device(self.device):     # (raises with the old table intact and still self.table)
@@ -541,29 +725,30 @@ class BatchedQLearningAgent:
         self.table._q2048_owner = bigger
         t0[1].record()
         t0[1].synchronize()
-        self.growths.append({"from_log2": self.capacity_log2, "to_log2": new, "rows": moved,
+        self.growths.append({"from_log2": self.capacity_log2, "to_log2": new, "rows": moved, "expected_rows": expected,
                              "ms": round(t0[0].elapsed_time(t0[1]), 3), "at_step": self.ctr})
         self.capacity_log2 = new
         self.invalidate_row_cache()
-        self._rows_known, self._rows_maybe = moved, 0
-        self._inserts_at_count = self._cumulative_inserts()
+        if moved != expected:
+            raise RuntimeError(f"Q-table self-check failed at the growth to 2^{new}: {moved} occupied slots moved, "
+                               f"{expected} rows created according to the kernels' counters")
         return moved
 
     def verify_table(self) -> dict:
         """Run-time check that no row was lost or duplicated: the slots occupied now == the rows counted
-        at the last count / import / growth + the rows the kernels say they created since
-        (Q2048_ST_INSERTS).  One streaming pass over the table (1.3 ms per 8 GiB), synchronising.
+        at the last count / import + the rows the kernels say they created since (Q2048_ST_INSERTS).  One
+        streaming pass over the table (1.3 ms per 8 GiB), synchronising -- for the end of a run, a checkpoint, a
+        test; every growth runs the same check on the table it leaves behind without the extra pass.
         Raises RuntimeError on a mismatch; returns the numbers."""
-        created = self._cumulative_inserts() - self._inserts_at_count
-        expect = self._rows_known + created
+        self.finish_growth()
+        expect = self._rows_exact()
         rows = self.table_size()
         timeouts = N.claim_timeouts()
         if rows != expect or timeouts:
             raise RuntimeError(f"Q-table self-check failed: {rows} occupied slots, expected {expect} "
-                               f"({self._rows_known} counted earlier + {created} created since); "
+                               f"({self._rows_base} counted earlier + {expect - self._rows_base} created since); "
                                f"{timeouts} 5x5 claim time-outs")
-        self._rows_known, self._rows_maybe = rows, 0
-        self._inserts_at_count = self._cumulative_inserts()
+        self._rebase_rows(rows)
         return {"rows": rows, "capacity_log2": self.capacity_log2, "load": rows / float(1 << self.capacity_log2)}
 
     # -- statistics / table access ---------------------------------------------------------
@@ -651,6 +836,7 @@ class BatchedQLearningAgent:
         self.stats_i.copy_(sd["stats_i"])
         self.stats_f.copy_(sd["stats_f"])
         self._inserts_folded = 0
+        self.finish_growth()
         self.invalidate_row_cache()
         self.table.zero_()
         if "table" in sd:
@@ -659,7 +845,7 @@ class BatchedQLearningAgent:
             self.table.copy_(sd["table"])
         else:
             self.import_rows(sd["keys"], sd["q"])
-        self._count_rows()
+        self._rebase_rows(self.table_size())
 
     def import_rows(self, keys: np.ndarray, q: np.ndarray) -> None:
         """Inserts (key, q[4]) rows exported by `export_rows` (any capacity that holds them)."""
@@ -669,7 +855,8 @@ class BatchedQLearningAgent:
             return
         self.invalidate_row_cache()
         while self.growable and rows * 2 > (1 << self.capacity_log2) and self.capacity_log2 < self.max_capacity_log2:
-            self.grow_table()
+            self.grow_table(min(self.max_capacity_log2,
+                                max(self.capacity_log2 + 1, int(np.ceil(np.log2(2.0 * rows))))))
         if rows * 2 > (1 << self.capacity_log2):
             raise ValueError("table too small for the checkpoint (load factor would exceed 0.5)")
         tk = torch.from_numpy(keys.view(np.int64)).to(self.device)
@@ -680,7 +867,7 @@ class BatchedQLearningAgent:
                                            _stream(self.device)), "table_import")
         if int(status.item()) & N.STATUS_TABLE_FULL:
             raise RuntimeError("table_import dropped rows (probe limit)")
-        self._count_rows()
+        self._rebase_rows(self.table_size())
 
     # -- argument plumbing -----------------------------------------------------------------
     def _boards(self, b) -> torch.Tensor:

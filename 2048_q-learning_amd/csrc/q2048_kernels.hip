@@ -19,10 +19,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
-
 
 #include "q2048.h"
 #include "q2048_core5.hpp"
@@ -1990,6 +1993,8 @@ const char* q2048_strerror(int code) {
     case Q2048_ERR_FLAGS: return "flag bits this entry point does not take";
     case Q2048_ERR_ALLOC: return "device memory could not be reserved, created or mapped";
     case Q2048_ERR_VERIFY: return "a table failed its self-check (a fresh table not all zeros, or rows lost while growing)";
+    case Q2048_ERR_BUSY: return "the table already takes part in a growth (finish or abort that one first)";
+    case Q2048_PENDING: return "still working (not an error)";
     default: return "unknown error";
   }
 }
@@ -2456,24 +2461,28 @@ int q2048_table_probe(q2048_slot* table, int cap_log2, int64_t lanes, int steps,
 // offsets inside one large reservation mapped, but hipMemSetAccess refused them -- invalid value -- whenever
 // their chunks were larger than 2 MiB and the reservation had not come back aligned to them.)
 namespace {
-struct Family { size_t chunk; int dev, cap0_log2, max_log2; };
+// (scratch: 64 B of device memory + 64 B of pinned host memory per family for the counters of a growth, and a
+// stream of its own -- allocated once, so that no growth ever calls hipMalloc / hipFree, which synchronise the device)
+struct Family { size_t chunk; int dev, cap0_log2, max_log2; u64* dev_scratch; unsigned long long* host_scratch; hipStream_t stream; };
 struct ChunkedTable { size_t bytes, chunk; int cap_log2; Family* fam; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_tables_mutex;
 std::map<void*, ChunkedTable> g_tables;
 std::vector<Family*> g_families;                         // kept for the life of the process
 
-// Chunk size of the table of capacity 2^cap_log2 in a family.  What hipMemCreate + hipMemMap + hipMemUnmap cost
-// PER CHUNK grows with the number of chunks a process holds (25 us each at 8192 chunks, 211 us each at 65 536:
-// mapping a 128 GiB table from 2 MiB chunks takes 13.8 s and un-mapping the 64 GiB one before it 2.7 s, while
-// moving its 10^9 rows takes 60 ms -- profiles/r04_growth_phases_2MiB_chunks.txt), so a table that GROWS is
-// mapped from at most kMaxChunks chunks of at least its family's size and at most kBigChunk: 2 MiB up to 2 GiB,
-// 8 / 16 / 32 MiB for 8 / 16 / 32 GiB, 64 MiB from 64 GiB on (2048 chunks for 128 GiB: creating 128 MiB
-// physically contiguous chunks took longer than mapping twice as many).  The chunk size itself does not decide how fast a table takes
-// scattered writes: six fresh 16 and 32 GiB tables each from 2, 8, 32 and 64 MiB chunks span 44-56 us per 2^20
-// (load + CAS + store) with every size's range inside the others' (profiles/r04_requests/
-// chunk_size_six_draws.txt) -- which allocation a table got matters, not how it was cut.  (A family of one --
-// q2048_table_alloc, the fixed tables the bench runs on and probes four of -- keeps the chunk size it asked for.)
-constexpr size_t kMaxChunks = 1024, kBigChunk = (size_t)64 << 20;
+// Chunk size of the table of capacity 2^cap_log2 in a family that can grow: its bytes / 1024, at least the family's
+// own size (2 MiB) and AT MOST 32 MiB.  What the virtual-memory calls cost, measured call by call
+// (tools/exp_vmm_cost.hip, profiles/r05_vmm_cost_by_chunk.txt, profiles/r05_vmm_cost_small_chunks.txt):
+//   hipMemCreate   ~4 us per chunk up to 32 MiB -- and 1.7 ms per 64 MiB chunk, 7-29 ms per 256 MiB chunk, 46 ms per
+//                  1 GiB chunk the first time: physically contiguous memory beyond 32 MiB is searched for, not found.
+//                  That, not the number of chunks, was round 4's 1.9 s for the step to 128 GiB (2048 chunks of 64 MiB);
+//   hipMemMap      5-13 us per chunk, hipMemUnmap 16 us, hipMemSetAccess 5 us -- growing slowly with the number of chunks
+//                  a process holds (2 MiB chunks for 128 GiB = 65 536 of them: 13.8 s, profiles/r04_growth_phases_2MiB_chunks.txt).
+// So a table is cut into as few chunks as 32 MiB allows: 1024 up to 32 GiB, 2048 for 64 GiB, 4096 for 128 GiB.
+// The chunk size itself does not decide how fast a table takes scattered writes (six fresh 16 and 32 GiB tables each
+// from 2, 8, 32 and 64 MiB chunks span 44-56 us per 2^20 load + CAS + store with every size's range inside the others',
+// profiles/r04_requests/chunk_size_six_draws.txt).  (A family of one -- q2048_table_alloc, the fixed tables the bench
+// runs on -- keeps the chunk size it asked for.)
+constexpr size_t kMaxChunks = 1024, kBigChunk = (size_t)32 << 20;
 size_t chunk_of(const Family& f, int cap_log2) {
   size_t c = f.chunk;
   if (f.max_log2 > f.cap0_log2)
@@ -2523,21 +2532,21 @@ struct DeviceGuard {
   }
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
-// occupied slots of a table, host-synchronous (a 16-byte device scratch per call)
-int count_rows_sync(const q2048_slot* table, int cap_log2, uint64_t* rows) {
-  u64* d = nullptr;
-  if (hipMalloc(&d, 16) != hipSuccess) return Q2048_ERR_ALLOC;
-  int rc = Q2048_OK;
-  if (hipMemset(d, 0, 16) != hipSuccess) rc = Q2048_ERR_LAUNCH;
-  if (rc == Q2048_OK) rc = q2048_table_count(table, cap_log2, reinterpret_cast<int64_t*>(d), nullptr);
-  unsigned long long v = 0;
-  if (rc == Q2048_OK && hipMemcpy(&v, d, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = Q2048_ERR_LAUNCH;
-  (void)hipFree(d);
-  *rows = (uint64_t)v;
-  return rc;
+// occupied slots of a table, counted on `stream` and waited for (scratch: 8 B of device memory, 8 B of pinned host
+// memory -- a family's own, so that nothing here calls hipMalloc / hipFree, which synchronise the whole device)
+int count_rows_on(const q2048_slot* table, int cap_log2, u64* dev8, unsigned long long* host8, hipStream_t stream,
+                  uint64_t* rows) {
+  if (hipMemsetAsync(dev8, 0, 8, stream) != hipSuccess) return Q2048_ERR_LAUNCH;
+  if (int rc = q2048_table_count(table, cap_log2, reinterpret_cast<int64_t*>(dev8), stream)) return rc;
+  if (hipMemcpyAsync(host8, dev8, 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return Q2048_ERR_LAUNCH;
+  *rows = (uint64_t)*host8;
+  return Q2048_OK;
 }
 // reserves, maps (from chunks of `chunk` bytes), zero-fills and verifies the table of capacity 2^cap_log2 of a
-// family; registers it
+// family, all of it on the family's own stream (never the caller's: this runs next to the caller's launches when a
+// growth is prepared); registers the table
 int map_table_with(Family* f, int cap_log2, size_t chunk, q2048_slot** out) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
@@ -2579,12 +2588,12 @@ int map_table_with(Family* f, int cap_log2, size_t chunk, q2048_slot** out) {
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   if (hipError_t e = hipMemSetAccess(va, t.bytes, &acc, 1)) { Q2048_MAP_FAIL("hipMemSetAccess", e); release_chunks(va, t.chunk, t.handles, mapped); return Q2048_ERR_ALLOC; }
-  if (hipError_t e = hipMemset(va, 0, t.bytes)) { Q2048_MAP_FAIL("hipMemset", e); release_chunks(va, t.chunk, t.handles, mapped); return Q2048_ERR_ALLOC; }
+  if (hipError_t e = hipMemsetAsync(va, 0, t.bytes, f->stream)) { Q2048_MAP_FAIL("hipMemsetAsync", e); release_chunks(va, t.chunk, t.handles, mapped); return Q2048_ERR_ALLOC; }
   // Silent row loss is the worst failure this library can have, and a table that does not read back as
   // zeros is how it would start (a slot that looks occupied swallows a key's probe sequence; stale
-  // translations were seen once, above): one streaming count of the fresh table, ~5 ms per 32 GiB.
+  // translations of a re-used range do exactly that, above): one streaming count of the fresh table, ~5 ms per 32 GiB.
   uint64_t rows = 0;
-  int rc = count_rows_sync(reinterpret_cast<q2048_slot*>(va), cap_log2, &rows);
+  int rc = count_rows_on(reinterpret_cast<q2048_slot*>(va), cap_log2, f->dev_scratch + 4, f->host_scratch + 4, f->stream, &rows);
   if (rc == Q2048_OK && rows != 0) rc = Q2048_ERR_VERIFY;
   if (rc != Q2048_OK) { release_chunks(va, t.chunk, t.handles, mapped); return rc; }
   std::lock_guard<std::mutex> lock(g_tables_mutex);
@@ -2599,101 +2608,9 @@ int map_table(Family* f, int cap_log2, q2048_slot** out) {
   if (rc == Q2048_ERR_ALLOC && chunk != f->chunk) rc = map_table_with(f, cap_log2, f->chunk, out);
   return rc;
 }
-}  // namespace
-
-int q2048_table_reserve(int cap_log2, int max_cap_log2, size_t chunk_bytes, q2048_slot** table_out) {
-  if (table_out == nullptr) return Q2048_ERR_NULL;
-  *table_out = nullptr;
-  if (cap_log2 < 4 || cap_log2 > 40 || max_cap_log2 < cap_log2 || max_cap_log2 > 40) return Q2048_ERR_SIZE;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return Q2048_ERR_LAUNCH;
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = dev;
-  size_t gran = 0;
-  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0)
-    return Q2048_ERR_ALLOC;
-  Family* f = new Family{chunk_bytes ? chunk_bytes : ((size_t)2 << 20), dev, cap_log2, max_cap_log2};
-  if (f->chunk % gran != 0 || (f->chunk & (f->chunk - 1)) != 0) { delete f; return Q2048_ERR_SIZE; }
-  const int rc = map_table(f, cap_log2, table_out);
-  if (rc != Q2048_OK) { delete f; return rc; }
-  std::lock_guard<std::mutex> lock(g_tables_mutex);
-  g_families.push_back(f);
-  return rc;
-}
-
-int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot** table_out) {
-  return q2048_table_reserve(cap_log2, cap_log2, chunk_bytes, table_out);
-}
-
-int q2048_table_grow(q2048_slot* table, int cap_log2, int new_cap_log2, int key_words, q2048_slot** table_out,
-                     int64_t* rows_moved, void* stream) {
-  if (table == nullptr || table_out == nullptr) return Q2048_ERR_NULL;
-  *table_out = nullptr;
-  if (key_words != 1 && key_words != 2) return Q2048_ERR_SIZE;
-  Family* f = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(g_tables_mutex);
-    auto it = g_tables.find(table);
-    if (it == g_tables.end()) return Q2048_ERR_NULL;      // not one of q2048_table_reserve's
-    if (it->second.cap_log2 != cap_log2) return Q2048_ERR_SIZE;
-    f = it->second.fam;
-  }
-  if (new_cap_log2 <= cap_log2 || new_cap_log2 > f->max_log2) return Q2048_ERR_SIZE;
-  DeviceGuard guard(f->dev);
-#ifdef Q2048_EXPERIMENTS   // Q2048_DEBUG_GROW=1: where a growth spends its time (stderr)
-  const bool dbg = getenv("Q2048_DEBUG_GROW") != nullptr;
-  auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-  double t_phase[5] = {now(), 0, 0, 0, 0};
-#define Q2048_GROW_MARK(k) do { if (dbg) t_phase[k] = now(); } while (0)
-#else
-#define Q2048_GROW_MARK(k) do { } while (0)
-#endif
-  q2048_slot* bigger = nullptr;
-  if (int e = map_table(f, new_cap_log2, &bigger)) return e;
-  Q2048_GROW_MARK(1);
-  u64* counters = nullptr;
-  int rc = hipMalloc(&counters, 16) == hipSuccess ? Q2048_OK : Q2048_ERR_ALLOC;
-  unsigned long long host[2] = {0ull, 0ull};
-  if (rc == Q2048_OK && hipMemsetAsync(counters, 0, 16, (hipStream_t)stream) != hipSuccess) rc = Q2048_ERR_LAUNCH;
-  if (rc == Q2048_OK) {
-    // ordered on `stream` behind whatever still works on the old table; 8 blocks of 4 waves per CU
-    const u64 cap = 1ull << cap_log2, mask = (1ull << new_cap_log2) - 1ull;
-    const u64 want = (cap + kBlock - 1) / kBlock;
-    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
-    if (key_words == 1)
-      hipLaunchKernelGGL(k_table_rehash<1>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, table, cap, bigger, mask, counters);
-    else
-      hipLaunchKernelGGL(k_table_rehash<2>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, table, cap, bigger, mask, counters);
-    rc = launch_status();
-  }
-  if (rc == Q2048_OK && (hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
-                         hipStreamSynchronize((hipStream_t)stream) != hipSuccess))
-    rc = Q2048_ERR_LAUNCH;
-  if (counters != nullptr) (void)hipFree(counters);
-  Q2048_GROW_MARK(2);
-  // every row must have moved, and the new table must hold exactly those rows
-  uint64_t rows = 0;
-  if (rc == Q2048_OK) rc = count_rows_sync(bigger, new_cap_log2, &rows);
-  if (rc == Q2048_OK && (host[1] != 0ull || rows != (uint64_t)host[0])) rc = Q2048_ERR_VERIFY;
-  if (rc != Q2048_OK) { q2048_table_free(bigger); return rc; }   // the old table is intact and stays the caller's
-  if (rows_moved != nullptr) *rows_moved = (int64_t)host[0];
-  Q2048_GROW_MARK(3);
-  if (int e = q2048_table_free(table)) return e;
-  Q2048_GROW_MARK(4);
-#ifdef Q2048_EXPERIMENTS
-  if (dbg)
-    fprintf(stderr, "[q2048 debug] grow 2^%d -> 2^%d, %llu rows: map + zero + verify %.1f ms, move %.1f ms, count %.1f ms, "
-            "free the old table %.1f ms\n", cap_log2, new_cap_log2, host[0], t_phase[1] - t_phase[0], t_phase[2] - t_phase[1],
-            t_phase[3] - t_phase[2], t_phase[4] - t_phase[3]);
-#endif
-  *table_out = bigger;
-  return Q2048_OK;
-}
-
-int q2048_table_free(q2048_slot* table) {
-  if (table == nullptr) return Q2048_OK;
+// takes a table out of the registry and gives its chunks back (the address range stays reserved, above).
+// `quiesced`: the caller knows that nothing on the device uses the table any more (a growth's event)
+int unregister_and_release(q2048_slot* table, bool quiesced) {
   ChunkedTable t;
   {
     std::lock_guard<std::mutex> lock(g_tables_mutex);
@@ -2703,12 +2620,13 @@ int q2048_table_free(q2048_slot* table) {
     g_tables.erase(it);
   }
   DeviceGuard guard(t.fam->dev);                          // the table's device, whatever the caller's current one is
-  if (hipDeviceSynchronize() != hipSuccess) return Q2048_ERR_LAUNCH;
+  if (!quiesced && hipDeviceSynchronize() != hipSuccess) return Q2048_ERR_LAUNCH;
 #ifdef Q2048_EXPERIMENTS
   // Measurement builds only (tools/chunk_debug.py): the round-3 free path that handed the address range
   // back, to look for what goes wrong when a range is re-used.  Q2048_DEBUG_VA_FREE = 1: unmap, release,
   // hipMemAddressFree; 2: the same and a device synchronize after it; 3: hipMemAddressFree only after
   // every chunk's hipMemRelease returned success, return codes printed.  Families of one table only.
+  // (tools/va_reuse_repro.hip shows the same loss with no library at all.)
   if (const char* mode = getenv("Q2048_DEBUG_VA_FREE")) {
     if (t.fam->cap0_log2 == t.fam->max_log2) {
       const int m = atoi(mode);
@@ -2726,6 +2644,314 @@ int q2048_table_free(q2048_slot* table) {
   }
 #endif
   return release_chunks(table, t.chunk, t.handles, t.handles.size()) ? Q2048_ERR_ALLOC : Q2048_OK;
+}
+
+// ONE host thread per process for the virtual-memory calls that a growth takes off the caller's critical path
+// (mapping the next table, un-mapping the previous one): tasks run one after the other, so the driver never sees
+// two of these call sequences at once.  Started by the first q2048_table_grow_begin; joined by an atexit handler
+// registered at that moment -- i.e. after the HIP runtime's own, so it runs before the runtime is torn down.
+class Worker {
+ public:
+  void post(std::function<void()> fn) {
+    std::unique_lock<std::mutex> lock(m_);
+    if (!started_) {
+      started_ = true;
+      th_ = std::thread([this] { run(); });
+      std::atexit([] { worker().stop(); });
+    }
+    q_.push_back(std::move(fn));
+    cv_.notify_all();
+  }
+  void drain() {                                          // until every posted task has run
+    std::unique_lock<std::mutex> lock(m_);
+    cv_.wait(lock, [this] { return q_.empty() && !busy_; });
+  }
+  void stop() {
+    {
+      std::unique_lock<std::mutex> lock(m_);
+      if (!started_ || stop_) return;
+      stop_ = true;
+      cv_.notify_all();
+    }
+    th_.join();
+  }
+  static Worker& worker() { static Worker* w = new Worker; return *w; }   // never destroyed
+
+ private:
+  void run() {
+    std::unique_lock<std::mutex> lock(m_);
+    for (;;) {
+      cv_.wait(lock, [this] { return stop_ || !q_.empty(); });
+      if (q_.empty()) return;                              // stop requested and nothing left to do
+      std::function<void()> fn = std::move(q_.front());
+      q_.pop_front();
+      busy_ = true;
+      lock.unlock();
+      fn();
+      lock.lock();
+      busy_ = false;
+      cv_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> q_;
+  std::thread th_;
+  bool started_ = false, stop_ = false, busy_ = false;
+};
+}  // namespace
+
+// A growth in progress (q2048_table_grow_begin .. _finish / _abort).  `state` is guarded by g_growth_mutex.
+struct q2048_growth {
+  q2048_slot* old_t = nullptr;
+  q2048_slot* bigger = nullptr;
+  int old_log2 = 0, new_log2 = 0;
+  Family* fam = nullptr;
+  int prepared = Q2048_PENDING;      // Q2048_PENDING while the worker maps the new table, then Q2048_OK or an error
+  bool committed = false, verify_count = false;
+  hipEvent_t moved = nullptr;        // recorded behind the rehash (and the counters' copy) on the caller's stream
+};
+
+namespace {
+std::mutex g_growth_mutex;
+std::condition_variable g_growth_cv;
+std::vector<q2048_growth*> g_growths;                    // begun and neither finished nor aborted
+
+q2048_growth* growth_of(const q2048_slot* table) {        // the growth a table takes part in (g_growth_mutex held)
+  for (q2048_growth* g : g_growths)
+    if (g->old_t == table || (g->bigger == table && g->committed)) return g;
+  return nullptr;
+}
+bool growth_is_live(const q2048_growth* g) {              // (g_growth_mutex held)
+  for (q2048_growth* x : g_growths) if (x == g) return true;
+  return false;
+}
+void growth_forget(q2048_growth* g) {                     // (g_growth_mutex held)
+  for (size_t k = 0; k < g_growths.size(); ++k)
+    if (g_growths[k] == g) { g_growths.erase(g_growths.begin() + (long)k); break; }
+  if (g->moved != nullptr) (void)hipEventDestroy(g->moved);
+  delete g;
+}
+int wait_prepared(q2048_growth* g) {                      // blocks until the worker is done with the new table
+  std::unique_lock<std::mutex> lock(g_growth_mutex);
+  g_growth_cv.wait(lock, [g] { return g->prepared != Q2048_PENDING; });
+  return g->prepared;
+}
+}  // namespace
+
+int q2048_table_reserve(int cap_log2, int max_cap_log2, size_t chunk_bytes, q2048_slot** table_out) {
+  if (table_out == nullptr) return Q2048_ERR_NULL;
+  *table_out = nullptr;
+  if (cap_log2 < 4 || cap_log2 > 40 || max_cap_log2 < cap_log2 || max_cap_log2 > 40) return Q2048_ERR_SIZE;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return Q2048_ERR_LAUNCH;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0)
+    return Q2048_ERR_ALLOC;
+  Family* f = new Family{chunk_bytes ? chunk_bytes : ((size_t)2 << 20), dev, cap_log2, max_cap_log2, nullptr, nullptr, nullptr};
+  if (f->chunk % gran != 0 || (f->chunk & (f->chunk - 1)) != 0) { delete f; return Q2048_ERR_SIZE; }
+  int rc = Q2048_OK;
+  if (hipMalloc(&f->dev_scratch, 64) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&f->host_scratch), 64, hipHostMallocDefault) != hipSuccess ||
+      hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess)
+    rc = Q2048_ERR_ALLOC;
+  if (rc == Q2048_OK) rc = map_table(f, cap_log2, table_out);
+  if (rc != Q2048_OK) {
+    if (f->stream != nullptr) (void)hipStreamDestroy(f->stream);
+    if (f->host_scratch != nullptr) (void)hipHostFree(f->host_scratch);
+    if (f->dev_scratch != nullptr) (void)hipFree(f->dev_scratch);
+    delete f;
+    return rc;
+  }
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
+  g_families.push_back(f);
+  return rc;
+}
+
+int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot** table_out) {
+  return q2048_table_reserve(cap_log2, cap_log2, chunk_bytes, table_out);
+}
+
+int q2048_table_grow_begin(q2048_slot* table, int cap_log2, int new_cap_log2, q2048_growth** growth_out) {
+  if (table == nullptr || growth_out == nullptr) return Q2048_ERR_NULL;
+  *growth_out = nullptr;
+  Family* f = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    auto it = g_tables.find(table);
+    if (it == g_tables.end()) return Q2048_ERR_NULL;      // not one of q2048_table_reserve's
+    if (it->second.cap_log2 != cap_log2) return Q2048_ERR_SIZE;
+    f = it->second.fam;
+  }
+  if (new_cap_log2 <= cap_log2 || new_cap_log2 > f->max_log2) return Q2048_ERR_SIZE;
+  q2048_growth* g = new q2048_growth;
+  g->old_t = table;
+  g->old_log2 = cap_log2;
+  g->new_log2 = new_cap_log2;
+  g->fam = f;
+  {
+    std::lock_guard<std::mutex> lock(g_growth_mutex);
+    for (q2048_growth* x : g_growths)
+      if (x->old_t == table) { delete g; return Q2048_ERR_BUSY; }   // one growth per table
+    g_growths.push_back(g);
+  }
+  Worker::worker().post([g] {
+    DeviceGuard guard(g->fam->dev);
+    q2048_slot* bigger = nullptr;
+    const int rc = map_table(g->fam, g->new_log2, &bigger);
+    std::lock_guard<std::mutex> lock(g_growth_mutex);
+    g->bigger = bigger;
+    g->prepared = rc;
+    g_growth_cv.notify_all();
+  });
+  *growth_out = g;
+  return Q2048_OK;
+}
+
+int q2048_table_grow_poll(q2048_growth* g) {
+  if (g == nullptr) return Q2048_ERR_NULL;
+  std::lock_guard<std::mutex> lock(g_growth_mutex);
+  if (!growth_is_live(g)) return Q2048_ERR_NULL;
+  if (!g->committed) return g->prepared;
+  const hipError_t e = hipEventQuery(g->moved);
+  return e == hipSuccess ? Q2048_OK : (e == hipErrorNotReady ? Q2048_PENDING : Q2048_ERR_LAUNCH);
+}
+
+int q2048_table_grow_commit(q2048_growth* g, int key_words, uint32_t flags, q2048_slot** table_out, void* stream) {
+  if (g == nullptr || table_out == nullptr) return Q2048_ERR_NULL;
+  *table_out = nullptr;
+  if (key_words != 1 && key_words != 2) return Q2048_ERR_SIZE;
+  if (flags & ~(uint32_t)Q2048_GROW_VERIFY_COUNT) return Q2048_ERR_FLAGS;
+  {
+    std::lock_guard<std::mutex> lock(g_growth_mutex);
+    if (!growth_is_live(g) || g->committed) return Q2048_ERR_NULL;
+    for (q2048_growth* x : g_growths)                     // the family's counters are in use until that one is finished
+      if (x != g && x->fam == g->fam && x->committed) return Q2048_ERR_BUSY;
+  }
+  int rc = wait_prepared(g);
+  Family* f = g->fam;
+  DeviceGuard guard(f->dev);
+  hipStream_t s = (hipStream_t)stream;
+  if (rc == Q2048_OK && hipEventCreateWithFlags(&g->moved, hipEventDisableTiming) != hipSuccess) rc = Q2048_ERR_LAUNCH;
+  if (rc == Q2048_OK && hipMemsetAsync(f->dev_scratch, 0, 32, s) != hipSuccess) rc = Q2048_ERR_LAUNCH;
+  if (rc == Q2048_OK) {
+    // ordered on `stream` behind whatever still works on the old table; 8 blocks of 4 waves per CU
+    const u64 cap = 1ull << g->old_log2, mask = (1ull << g->new_log2) - 1ull;
+    const u64 want = (cap + kBlock - 1) / kBlock;
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    if (key_words == 1)
+      hipLaunchKernelGGL(k_table_rehash<1>, dim3(blocks), dim3(kBlock), 0, s, g->old_t, cap, g->bigger, mask, f->dev_scratch);
+    else
+      hipLaunchKernelGGL(k_table_rehash<2>, dim3(blocks), dim3(kBlock), 0, s, g->old_t, cap, g->bigger, mask, f->dev_scratch);
+    rc = launch_status();
+  }
+  g->verify_count = (flags & Q2048_GROW_VERIFY_COUNT) != 0u;
+  if (rc == Q2048_OK && g->verify_count)
+    rc = q2048_table_count(g->bigger, g->new_log2, reinterpret_cast<int64_t*>(f->dev_scratch + 2), s);
+  if (rc == Q2048_OK && (hipMemcpyAsync(f->host_scratch, f->dev_scratch, 32, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                         hipEventRecord(g->moved, s) != hipSuccess))
+    rc = Q2048_ERR_LAUNCH;
+  if (rc != Q2048_OK) {                                   // the old table is intact and stays the caller's
+    if (g->bigger != nullptr) {
+      (void)hipStreamSynchronize(s);
+      (void)unregister_and_release(g->bigger, false);
+    }
+    std::lock_guard<std::mutex> lock(g_growth_mutex);
+    growth_forget(g);
+    return rc;
+  }
+  std::lock_guard<std::mutex> lock(g_growth_mutex);
+  g->committed = true;
+  *table_out = g->bigger;
+  return Q2048_OK;
+}
+
+int q2048_table_grow_finish(q2048_growth* g, int64_t* rows_moved) {
+  if (g == nullptr) return Q2048_ERR_NULL;
+  {
+    std::lock_guard<std::mutex> lock(g_growth_mutex);
+    if (!growth_is_live(g) || !g->committed) return Q2048_ERR_NULL;
+  }
+  Family* f = g->fam;
+  int rc = Q2048_OK;
+  {
+    DeviceGuard guard(f->dev);
+    if (hipEventSynchronize(g->moved) != hipSuccess) rc = Q2048_ERR_LAUNCH;
+  }
+  const unsigned long long moved = f->host_scratch[0], failed = f->host_scratch[1], counted = f->host_scratch[2];
+  // every occupied slot of the old table must have found its place, and (when asked for) the new table must hold
+  // exactly those rows
+  if (rc == Q2048_OK && (failed != 0ull || (g->verify_count && counted != moved))) rc = Q2048_ERR_VERIFY;
+  if (rows_moved != nullptr) *rows_moved = (int64_t)moved;
+  q2048_slot* old_t = g->old_t;
+  {
+    std::lock_guard<std::mutex> lock(g_growth_mutex);
+    growth_forget(g);
+  }
+  // nothing on the device reads the old table any more (the event): its chunks go back from the worker thread --
+  // 16 us per chunk that the caller does not wait for.  On Q2048_ERR_VERIFY both tables stay mapped.
+  if (rc == Q2048_OK) Worker::worker().post([old_t] { (void)unregister_and_release(old_t, true); });
+  return rc;
+}
+
+int q2048_table_grow_abort(q2048_growth* g) {
+  if (g == nullptr) return Q2048_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_growth_mutex);
+    if (!growth_is_live(g) || g->committed) return Q2048_ERR_NULL;
+  }
+  const int rc = wait_prepared(g);
+  q2048_slot* bigger = g->bigger;
+  {
+    std::lock_guard<std::mutex> lock(g_growth_mutex);
+    growth_forget(g);
+  }
+  if (rc == Q2048_OK && bigger != nullptr) return unregister_and_release(bigger, true);   // never used by any kernel
+  return Q2048_OK;
+}
+
+int q2048_table_grow(q2048_slot* table, int cap_log2, int new_cap_log2, int key_words, q2048_slot** table_out,
+                     int64_t* rows_moved, void* stream) {
+  if (table == nullptr || table_out == nullptr) return Q2048_ERR_NULL;
+  *table_out = nullptr;
+  if (key_words != 1 && key_words != 2) return Q2048_ERR_SIZE;
+  q2048_growth* g = nullptr;
+  if (int e = q2048_table_grow_begin(table, cap_log2, new_cap_log2, &g)) return e;
+  q2048_slot* bigger = nullptr;
+  if (int e = q2048_table_grow_commit(g, key_words, Q2048_GROW_VERIFY_COUNT, &bigger, stream)) return e;
+  if (int e = q2048_table_grow_finish(g, rows_moved)) {   // the old table is intact and stays the caller's
+    (void)unregister_and_release(bigger, false);
+    return e;
+  }
+  Worker::worker().drain();                               // host-synchronous: the old table's memory is back
+  *table_out = bigger;
+  return Q2048_OK;
+}
+
+int q2048_table_free(q2048_slot* table) {
+  if (table == nullptr) return Q2048_OK;
+  // a table that takes part in a growth: the growth is resolved first (an unprepared / uncommitted one is
+  // aborted, a committed one finished), so that a caller tearing down in any order frees everything once
+  for (;;) {
+    q2048_growth* g = nullptr;
+    bool committed = false, is_old = false;
+    {
+      std::lock_guard<std::mutex> lock(g_growth_mutex);
+      g = growth_of(table);
+      if (g != nullptr) { committed = g->committed; is_old = g->old_t == table; }
+    }
+    if (g == nullptr) break;
+    if (!committed) { (void)q2048_table_grow_abort(g); continue; }
+    const int rc = q2048_table_grow_finish(g, nullptr);
+    Worker::worker().drain();
+    if (is_old) return rc == Q2048_OK ? Q2048_OK : unregister_and_release(table, false);   // finish released it
+  }
+  Worker::worker().drain();                               // (a release of this very table may be on its way)
+  return unregister_and_release(table, false);
 }
 
 int q2048_table_count(const q2048_slot* table, int cap_log2, int64_t* count, void* stream) {

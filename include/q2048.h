@@ -44,10 +44,12 @@
 extern "C" {
 #endif
 
-#define Q2048_ABI_VERSION 4 /* 3: flag bits outside the ABI are refused (Q2048_ERR_FLAGS), Q2048_ST_CAS_FALLBACK,
+#define Q2048_ABI_VERSION 5 /* 3: flag bits outside the ABI are refused (Q2048_ERR_FLAGS), Q2048_ST_CAS_FALLBACK,
                                deterministic step sorted by a hash of (state, action)
                                4: q2048_fused_rollout_opts (row cache + statistics mirror of the fused
-                               rollout), q2048_table_grow, q2048_table_alloc verifies its zero fill */
+                               rollout), q2048_table_grow, q2048_table_alloc verifies its zero fill
+                               5: growth off the caller's critical path (q2048_table_grow_begin / _poll /
+                               _commit / _finish / _abort) */
 
 /* return codes */
 #define Q2048_OK 0
@@ -61,6 +63,8 @@ extern "C" {
 #define Q2048_ERR_ALLOC (-8)       /* q2048_table_alloc: memory could not be reserved / created / mapped */
 #define Q2048_ERR_VERIFY (-9)      /* a table failed its self-check: a freshly mapped table did not read back as
                                       zeros, or q2048_table_grow did not find every row in the new table */
+#define Q2048_ERR_BUSY (-10)       /* the table already takes part in a growth */
+#define Q2048_PENDING 1            /* q2048_table_grow_poll: still working (not an error) */
 
 /* bits of the device status word */
 #define Q2048_STATUS_BAD_ACTION 1u    /* an action outside 0..3 was passed (lane left untouched) */
@@ -383,32 +387,67 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  * wrongly looks occupied is how rows would get lost silently).  Host-synchronous.
  *
  * A table that grows -- the reference's defaultdict (Agent/main.py:16) has no capacity:
- * q2048_table_reserve maps a table of 2^cap_log2 slots that may grow up to 2^max_cap_log2;
- * q2048_table_grow(table, cap_log2, new_cap_log2, key_words, &bigger, &rows, stream) maps the table of
- * capacity 2^new_cap_log2 (cap_log2 < new_cap_log2 <= max_cap_log2) onto fresh chunks in an address range
- * of its own, moves every row over in one streaming pass ordered on `stream` (the rows keep their values;
- * their slots change: zero-fill any row cache), checks that the new table holds exactly the rows
- * the old one held (Q2048_ERR_VERIFY otherwise: the old table is then intact and still the caller's), and
- * releases the old table.  The table's ADDRESS changes: *table_out is the table from then on.
- * rows_moved (host int64, may be NULL) receives the number of rows.  Host-synchronous; while both
- * tables exist the device holds 1.5 x the new one.  A table of a family that can grow is mapped from at
- * most 1024 chunks of at most 64 MiB (2 MiB up to 2 GiB, 8 / 16 / 32 MiB for 8 / 16 / 32 GiB, 64 MiB
- * beyond): what the virtual-memory
- * calls cost per chunk grows with the number of chunks a process holds, and a 128 GiB table in 2 MiB chunks
- * takes 14 s to map while moving its 10^9 rows takes 60 ms (profiles/r04_growth_phases_*.txt).  q2048_table_alloc
- * keeps the chunk size it is asked for.  The caller decides when: between launches, when
- * rows created / capacity passes its load limit (the rollout's step slows from 46.7 to 66.3 us as the
- * load goes from 0.12 to 0.54, profiles/r03_load_curve.jsonl).
+ * q2048_table_reserve maps a table of 2^cap_log2 slots that may grow up to 2^max_cap_log2 (and allocates the
+ * family's 64 bytes of scratch and its private stream: nothing below calls hipMalloc / hipFree).  Growing =
+ * mapping the table of capacity 2^new_cap_log2 (cap_log2 < new_cap_log2 <= max_cap_log2) onto fresh chunks in
+ * an address range of its own, moving every row over in one streaming pass (the rows keep their values; their
+ * slots change: zero-fill any row cache), and releasing the old table.  The table's ADDRESS changes.
+ *
+ * Off the caller's critical path (the reference's dict grows without stopping the loop, Agent/main.py:16,91-101):
+ *   q2048_table_grow_begin(table, cap_log2, new_cap_log2, &g)   returns at once; ONE host thread of the library
+ *       (started by the first call, joined at exit) reserves, creates, maps, zero-fills and verifies the new table
+ *       on the family's own stream while the caller keeps launching rollouts on the old one: 31 ms for 32 GiB,
+ *       119 ms for 128 GiB next to a stream of launches that slow by 16 % meanwhile
+ *       (profiles/r05_vmm_cost_small_chunks.txt).
+ *   q2048_table_grow_poll(g)      Q2048_OK: the next call (commit, or finish after a commit) will not block;
+ *       Q2048_PENDING: it would; < 0: the preparation failed (commit returns the same code and ends the growth).
+ *   q2048_table_grow_commit(g, key_words, flags, &bigger, stream)   waits for the preparation if need be, then
+ *       enqueues the move (k_table_rehash, 18 G rows/s) on `stream`, behind whatever the caller queued on the old
+ *       table, and returns the new table WITHOUT waiting for it: every launch queued on `stream` from here on
+ *       takes *bigger.  flags: Q2048_GROW_VERIFY_COUNT also counts the new table's rows behind the move (one more
+ *       streaming pass, 21 ms per 128 GiB).  On error the old table is intact and still the caller's, g is gone.
+ *   q2048_table_grow_finish(g, &rows)   waits for the move, checks it -- every occupied slot of the old table found
+ *       its place (and, with VERIFY_COUNT, the new table holds exactly that many rows): Q2048_ERR_VERIFY otherwise,
+ *       both tables then stay mapped -- and hands the old table to the host thread for release (16 us per chunk
+ *       the caller does not wait for).  The old table must not be touched after a successful finish.  rows (host
+ *       int64, may be NULL) = rows moved = the occupied slots of the old table: compare it with the rows the
+ *       kernels reported (Q2048_ST_INSERTS) and the old table is verified end to end.
+ *   q2048_table_grow_abort(g)     before the commit: the prepared table is released, the old one untouched.
+ * One growth per table at a time (Q2048_ERR_BUSY); the next growth of the NEW table may begin right after the
+ * commit, its commit only after the previous finish.  q2048_table_grow(...) is begin + commit(VERIFY_COUNT) +
+ * finish + wait for the release in one host-synchronous call.  While both tables exist the device holds both.
+ *
+ * Chunk sizes: a table of a family that can grow is cut into as few chunks as 32 MiB allows (2 MiB up to 2 GiB,
+ * bytes / 1024 up to 32 GiB, 32 MiB beyond: 4096 chunks for 128 GiB).  hipMemMap / hipMemUnmap / hipMemSetAccess
+ * cost 5-16 us per chunk (more, the more chunks a process holds: 2 MiB chunks for 128 GiB took 13.8 s,
+ * profiles/r04_growth_phases_2MiB_chunks.txt); what hipMemCreate costs depends on the state of the device's free
+ * memory, not on the chunk: 4-30 us per chunk on memory that has been free for a while, seconds per table (at any
+ * chunk size from 8 MiB to 1 GiB) when the driver hands out memory that was released moments before, by this or
+ * by the previous process (profiles/r05_vmm_cost_by_chunk.txt, r05_vmm_cost_small_chunks.txt) -- which is what
+ * round 4's 1.9 s for the step to 128 GiB was.  q2048_table_alloc keeps the chunk size it is asked for.
+ * The caller decides when to grow: between launches, when rows created / capacity passes its load limit (the
+ * rollout's step slows from 46.7 to 66.3 us as the load goes from 0.12 to 0.54, profiles/r03_load_curve.jsonl).
  *
  * q2048_table_free unmaps a table's chunks and releases their physical memory (it synchronises the
- * table's device first, whatever the calling thread's current device is).  THE ADDRESS RANGE STAYS
- * RESERVED until the process ends and no part of it is ever mapped a second time -- a range that was
- * freed, reserved again and mapped onto new chunks was seen to serve stale translations on ROCm 7.2
- * (the third table of a process lost 1-15 % of its rows; tools/chunk_debug.py).  A process therefore
- * accumulates reserved address space -- 2^-12 of its 47-bit space per 32 GiB table -- not memory.
- * All four are thread-safe. */
+ * table's device first, whatever the calling thread's current device is; a growth the table takes part in is
+ * resolved first: aborted if uncommitted, finished if committed).  THE ADDRESS RANGE STAYS
+ * RESERVED until the process ends and no part of it is ever mapped a second time -- a range that is
+ * freed, reserved again and mapped onto new chunks serves stale translations on ROCm 7.2: tables on a re-used
+ * range lose 0.01-1.3 % of the rows written to them, with every HIP call returning success.  Library-free
+ * reproducer: tools/va_reuse_repro.hip (152 lines of HIP; profiles/r05_va_reuse_repro.txt: 0 of 8 tables lose
+ * rows on fresh ranges, 4 of 8 on a re-used one, 1 of 8 with a device synchronize after the free).  A process
+ * therefore accumulates reserved address space -- 2^-12 of its 47-bit space per 32 GiB table -- not memory.
+ * All of these are thread-safe. */
+#define Q2048_GROW_VERIFY_COUNT 1u
+typedef struct q2048_growth q2048_growth; /* opaque: a growth between begin and finish / abort */
 int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot **table_out);
 int q2048_table_reserve(int cap_log2, int max_cap_log2, size_t chunk_bytes, q2048_slot **table_out);
+int q2048_table_grow_begin(q2048_slot *table, int cap_log2, int new_cap_log2, q2048_growth **growth_out);
+int q2048_table_grow_poll(q2048_growth *growth);
+int q2048_table_grow_commit(q2048_growth *growth, int key_words, uint32_t flags, q2048_slot **table_out,
+                            void *stream);
+int q2048_table_grow_finish(q2048_growth *growth, int64_t *rows_moved);
+int q2048_table_grow_abort(q2048_growth *growth);
 int q2048_table_grow(q2048_slot *table, int cap_log2, int new_cap_log2, int key_words,
                      q2048_slot **table_out, int64_t *rows_moved, void *stream);
 int q2048_table_free(q2048_slot *table);

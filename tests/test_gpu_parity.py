@@ -1913,25 +1913,55 @@ def test_table_grows_like_the_reference_defaultdict(pkg, n):
         return k[o], q[o]
 
     e0, a0 = mk(26)
-    e1, a1 = mk("auto", initial_capacity_log2=21)
-    assert a1.growable and a1.capacity_log2 == 21 and a1.placement["mode"] == "chunks"
+    # the growth off the critical path (round 5: q2048_table_grow_begin / _commit / _finish; the next table mapped
+    # by the library's host thread while launches go on) in doubling steps, the same in the default fourfold steps
+    # without prefetch, and round 4's host-synchronous q2048_table_grow: one result
+    e1, a1 = mk("auto", initial_capacity_log2=21, growth_step_log2=1)
+    e3, a3 = mk("auto", initial_capacity_log2=21, growth_step_log2=1, async_growth=False)
+    e4, a4 = mk("auto", initial_capacity_log2=21, prefetch_growth=False, verify_growth=True)
+    for a in (a1, a3, a4):
+        assert a.growable and a.capacity_log2 == 21 and a.placement["mode"] == "chunks"
+    assert a1._growth is not None and a3._growth is None and a4._growth is None      # prefetch: begun at construction
     seen = {a1.table.data_ptr()}
     for _ in range(launches):
         a0.fused_rollout(e0, S)
-        a1.fused_rollout(e1, S)
-        chk = a1.verify_table()                                   # occupied slots == rows created, every launch
-        assert chk["load"] <= 0.5 + 2.0 * B * S / (1 << a1.capacity_log2)
+        for e, a in ((e1, a1), (e3, a3), (e4, a4)):
+            a.fused_rollout(e, S)
+            chk = a.verify_table()                                # occupied slots == rows created, every launch
+            assert chk["load"] <= 0.85                            # (soft limit 0.5, hard limit 0.75 + one launch)
         if a1.table.data_ptr() not in seen:
             seen.add(a1.table.data_ptr())
     assert len(a1.growths) >= 2 and 2 <= len(seen) <= len(a1.growths) + 1, a1.growths   # (a call may double twice)
     assert [g["to_log2"] - g["from_log2"] for g in a1.growths] == [1] * len(a1.growths)
-    assert torch.equal(e0.boards, e1.boards) and torch.equal(e0.aux, e1.aux)
+    assert [g["to_log2"] - g["from_log2"] for g in a3.growths] == [1] * len(a3.growths) and len(a3.growths) >= 2
+    assert a4.growths and all(1 <= g["to_log2"] - g["from_log2"] <= 2 for g in a4.growths)
+    assert all(g["rows"] == g["expected_rows"] for a in (a1, a3, a4) for g in a.growths)
     (k0, q0), (k1, q1) = table(a0), table(a1)
     assert np.array_equal(k0, k1) and np.array_equal(q0, q1)      # every row, bit for bit
+    for e, a in ((e1, a1), (e3, a3), (e4, a4)):
+        assert torch.equal(e0.boards, e.boards) and torch.equal(e0.aux, e.aux)
+        k, q = table(a)
+        assert np.array_equal(k0, k) and np.array_equal(q0, q)
     s0, s1 = a0.stats(), a1.stats()
     assert s0["inserts"] == s1["inserts"] == len(q1) == a1.table_size() and s1["drops"] == s0["drops"] == 0
     assert a1.check_status() == 0 and pkg._native.claim_timeouts() == 0
-    print(f"[grow {n}x{n}] {a1.growths}")
+    print(f"[grow {n}x{n}] async {a1.growths}\n  sync {a3.growths}\n  fourfold, no prefetch, counted {a4.growths}")
+    # the C entry points of the asynchronous growth: one growth per table, abort gives the prepared table back
+    L = pkg._native.lib()
+    own, g1, g2, out = a4.table._q2048_owner, C.c_void_p(), C.c_void_p(), C.c_void_p()
+    if a4._growth is not None:
+        a4._growth.abort()
+        a4._growth = None
+    a4.finish_growth()
+    if a4.capacity_log2 < a4.max_capacity_log2:
+        assert L.q2048_table_grow_begin(own.ptr, a4.capacity_log2, a4.capacity_log2 + 1, C.byref(g1)) == 0
+        assert L.q2048_table_grow_begin(own.ptr, a4.capacity_log2, a4.capacity_log2 + 1, C.byref(g2)) == pkg._native.ERR_BUSY
+        assert L.q2048_table_grow_finish(g1, None) == -1          # not committed
+        assert L.q2048_table_grow_commit(g1, 3, 0, C.byref(out), None) == -2 and L.q2048_table_grow_commit(g1, 1, 8, C.byref(out), None) == -7
+        assert L.q2048_table_grow_abort(g1) == 0 and L.q2048_table_grow_abort(g1) == -1 and L.q2048_table_grow_poll(g1) == -1
+        assert L.q2048_table_grow_begin(own.ptr, a4.capacity_log2, a4.max_capacity_log2 + 1, C.byref(g1)) == -2
+    assert a4.verify_table()["rows"] == len(q1)
+    del a3, a4, e3, e4
     # a fixed table cannot grow; a growable one not beyond its range
     with pytest.raises(RuntimeError):
         a0.grow_table()
@@ -1949,7 +1979,7 @@ def test_table_grows_like_the_reference_defaultdict(pkg, n):
     Bs = 1 << 16
     es = pkg.BatchedGame2048Env(Bs, board_size=n, seed=seed, env_id0=id0, device=DEV)
     ag = pkg.BatchedQLearningAgent(1000, exploration_rate=1.0, capacity_log2="auto", initial_capacity_log2=17,
-                                   seed=seed, env_id0=id0, device=DEV, board_size=n)
+                                   growth_step_log2=1, seed=seed, env_id0=id0, device=DEV, board_size=n)
     ef = pkg.BatchedGame2048Env(Bs, board_size=n, seed=seed, env_id0=id0, device=DEV)
     af = pkg.BatchedQLearningAgent(1000, exploration_rate=1.0, capacity_log2=24, seed=seed, env_id0=id0,
                                    device=DEV, board_size=n)
@@ -1963,6 +1993,7 @@ def test_table_grows_like_the_reference_defaultdict(pkg, n):
             s = e.reset(d)
         a.deterministic_rollout(e, 4)
         a.fused_rollout(e, 6)
+    ag.finish_growth()
     assert len(ag.growths) >= 3 and torch.equal(es.boards, ef.boards)
     kg, kf = ag.export_rows()[0], af.export_rows()[0]
     kg, kf = kg.reshape(len(kg), -1), kf.reshape(len(kf), -1)
@@ -2258,6 +2289,45 @@ def test_train_resume_continues_the_run(tmp_path):
     # epochs 4..7 of a 40-epoch schedule are its first phase (floor 1.5 * epsilon_min = 0.015, Agent/main.py:46-48);
     # the saved run's own limits (first phase over at epoch 3, last phase from epoch 8) would give 0.011 and 0.01
     assert int(rows("p3.csv")[-1][0]) >= 8 and abs(eps3[-1] - 0.015) < 1e-6
+
+
+def test_train_default_growing_table_save_and_resume(tmp_path):
+    """`train.py` WITHOUT --capacity-log2 (the default since round 4: a table that grows; ADVICE r4: only profile
+    logs backed that path).  A small first capacity makes the table grow several times inside the run, off the
+    critical path (--growth async, the default) and host-synchronously (--growth sync): in deterministic mode both
+    print the same report rows and save bit-identical tables; a save at epoch 3 resumed into a fresh growing table
+    ends in the same table as the uninterrupted run; the end-of-run check (occupied slots == rows created) passes."""
+    release_cached_device_memory()
+    import csv
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    common = ["--num-envs", "2048", "--steps-per-launch", "32", "--report-every", "1", "--initial-capacity-log2", "15",
+              "--deterministic", "--epsilon", "0.9", "--seed", "4", "--episodes", "6"]
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(REPO, "train.py"), *common, *a],  # noqa: E731
+                                    capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    rows = lambda f: [r[:8] for r in list(csv.reader(open(tmp_path / f)))[1:]]  # noqa: E731
+    pa = run("--save", "async.pt", "--log", "async.csv")
+    assert pa.returncode == 0, pa.stderr[-2000:]
+    ps = run("--growth", "sync", "--save", "sync.pt", "--log", "sync.csv")
+    assert ps.returncode == 0, ps.stderr[-2000:]
+    for p in (pa, ps):
+        assert p.stdout.count("table grew") >= 2 and "table check passed" in p.stdout, p.stdout[-1500:]
+    assert "host blocked" in pa.stdout and "host-synchronous" in ps.stdout
+    assert rows("async.csv") == rows("sync.csv")
+    p1 = run("--stop-epoch", "3", "--save", "part.pt", "--log", "p1.csv")
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    p2 = run("--resume", "part.pt", "--save", "resumed.pt", "--log", "p2.csv")
+    assert p2.returncode == 0 and "table check passed" in p2.stdout, p2.stderr[-2000:]
+    assert rows("p1.csv") + rows("p2.csv") == rows("async.csv")
+    sd = {f: torch.load(tmp_path / f, map_location="cpu", weights_only=False) for f in ("async.pt", "sync.pt", "resumed.pt")}
+    o = {f: np.argsort(d["keys"]) for f, d in sd.items()}
+    for f in ("sync.pt", "resumed.pt"):
+        assert np.array_equal(sd["async.pt"]["keys"][o["async.pt"]], sd[f]["keys"][o[f]])
+        assert np.array_equal(sd["async.pt"]["q"][o["async.pt"]], sd[f]["q"][o[f]])
+    assert sd["async.pt"]["capacity_log2"] > 15 and len(sd["async.pt"]["keys"]) > (1 << 14)
 
 
 def test_train_self_launched_two_ranks_share_one_gpu(tmp_path):

@@ -49,7 +49,20 @@ def parse_args(argv=None):
     p.add_argument("--steps-per-launch", type=int, default=64)
     p.add_argument("--capacity-log2", type=int, default=0,
                    help="Q-table slots = 2^n, fixed; 0 (default) = a table that grows like the reference's "
-                        "defaultdict: it starts at 2^28 slots and doubles whenever half of it is in use")
+                        "defaultdict, without stopping the loop: it starts at --initial-capacity-log2 slots and "
+                        "grows fourfold whenever half of it is in use (the next table is mapped by a host thread "
+                        "while the rollouts go on; the rows move between two launches)")
+    p.add_argument("--initial-capacity-log2", type=int, default=0,
+                   help="first capacity of the growing table; 0 (default) = 2^30 slots (32 GiB) when that is at most "
+                        "an eighth of the free device memory, else the largest power of two that is")
+    p.add_argument("--growth", choices=["async", "sync"], default="async",
+                   help="async (default): growth off the critical path (q2048_table_grow_begin / _commit / _finish); "
+                        "sync: the host-synchronous q2048_table_grow (same table, bit for bit)")
+    p.add_argument("--verify-every", type=int, default=0,
+                   help="batched mode: every N reports also count the table's occupied slots against the rows the "
+                        "kernels created (one streaming pass, synchronising).  0 (default): the check runs where it "
+                        "is free or needed -- at every growth (on the table left behind), before --save and at the "
+                        "end of the run")
     p.add_argument("--strict-td", action="store_true", help="compare-and-swap TD writes (bounded: after 16 lost "
                    "races an update is stored plainly and counted in the statistics)")
     p.add_argument("--deterministic", action="store_true",
@@ -162,7 +175,9 @@ def train_batched(args, pkg):
     else:
         agent = pkg.BatchedQLearningAgent(args.episodes, 4, args.alpha, args.gamma, args.epsilon,
                                           args.epsilon_min, cap, dev, args.seed, shard.env_id0,
-                                          strict_td=args.strict_td, board_size=args.board_size)
+                                          strict_td=args.strict_td, board_size=args.board_size,
+                                          initial_capacity_log2=args.initial_capacity_log2 or "auto",
+                                          async_growth=args.growth == "async")
     if args.deterministic and args.agent != "hash":
         raise SystemExit("--deterministic applies to the hash-table agent")
     if (args.save or args.resume) and args.agent != "hash":
@@ -199,7 +214,7 @@ def train_batched(args, pkg):
         total_eps = pkg.stats_dict(*reducer.wait())["episodes"]
     stop_epoch = min(args.episodes, args.stop_epoch) if args.stop_epoch else args.episodes
     target = stop_epoch * shard.total_envs
-    best_tile, grown = 0, 0
+    best_tile, grown, reports = 0, 0, 0
     agent.train_progress = {"epoch": epoch}
     agent.train_env = env
     while total_eps < target:
@@ -225,13 +240,13 @@ def train_batched(args, pkg):
             epoch += 1
         agent.train_progress = {"epoch": epoch}
         best_tile = max(st["max_tile_hist"], default=0)
+        reports += 1
         if args.agent == "hash":
-            check = agent.verify_table()                  # occupied slots == rows the kernels created: every report
-            while len(agent.growths) > grown:
-                g = agent.growths[grown]
-                grown += 1
-                print(f"[rank {rank}] table grew 2^{g['from_log2']} -> 2^{g['to_log2']} slots at step "
-                      f"{g['at_step']}: {g['rows']} rows moved in {g['ms']:.1f} ms", flush=True)
+            # occupied slots == rows the kernels created: every growth checks the table it leaves behind (no extra
+            # pass); a full count only when asked for (--verify-every), before --save and at the end of the run
+            if args.verify_every and reports % args.verify_every == 0:
+                agent.verify_table()
+            grown = _report_growths(agent, grown, rank)
         if rank == 0:
             rate = st["steps"] / (time.time() - t0)
             with open(args.log, mode="a", newline="") as fh:
@@ -244,7 +259,22 @@ def train_batched(args, pkg):
         if args.max_steps and env.ctr >= args.max_steps:
             break
     agent.check_status()
+    if args.agent == "hash":
+        check = agent.verify_table()                      # (waits for a growth still in flight and checks it too)
+        grown = _report_growths(agent, grown, rank)
+        print(f"[rank {rank}] table check passed: {check['rows']} rows == rows created, 2^{check['capacity_log2']} "
+              f"slots, load {check['load']:.3f}", flush=True)
     return agent
+
+
+def _report_growths(agent, grown, rank) -> int:
+    while len(agent.growths) > grown:
+        g = agent.growths[grown]
+        grown += 1
+        print(f"[rank {rank}] table grew 2^{g['from_log2']} -> 2^{g['to_log2']} slots at step {g['at_step']}: "
+              f"{g['rows']} rows moved in {g['ms']:.1f} ms on the stream"
+              + (f", host blocked {g['host_ms']:.1f} ms" if "host_ms" in g else " (host-synchronous)"), flush=True)
+    return grown
 
 
 def _resume_schedule(agent, sd, args, total_envs) -> int:
