@@ -1,8 +1,12 @@
-"""ctypes binding of libq2048_hip.so (the C ABI of include/q2048.h).
+"""ctypes binding of libq2048_hip.so (the C ABI of include/q2048.h) -- and, for the explicit device
+"cpu" only, of libq2048_host.so: the same ABI on host memory, compiled from the same per-lane
+arithmetic (csrc/q2048_host.cpp).
 
-There is no CPU fallback: if the shared library is missing or does not export the ABI this
-module raises, and every op of the package fails loudly.  `build()` compiles it in-tree with
-hipcc for gfx950 (cross-compiles without a GPU)."""
+There is no fallback in either direction: a library that is missing or does not export the ABI
+raises, every op of the package fails loudly, and which library a call goes to is decided by the
+device the caller named (`lib_for`), never by what happens to be available.  `build()` compiles the
+HIP library in-tree with hipcc for gfx950 (cross-compiles without a GPU), `build_host()` the host
+library with g++."""
 from __future__ import annotations
 
 import ctypes as C
@@ -17,6 +21,8 @@ LIB_PATH = os.environ.get("Q2048_LIB_PATH") or os.path.join(CSRC, "libq2048_hip.
 # the measurement build (-DQ2048_EXPERIMENTS: extra flag bits 8..23 for ablations and sort widths);
 # tools/ and two parity tests load it explicitly, the package never does
 EXPERIMENTS_LIB_PATH = os.path.abspath(os.path.join(_PKG, "..", "tools", "variants", "libq2048_hip_exp.so"))
+HOST_LIB_PATH = os.path.join(CSRC, "libq2048_host.so")
+HOST_DEPS = ["q2048_host.cpp", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc"]
 SOURCES = ["q2048_kernels.hip"]
 DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc"]
 
@@ -81,6 +87,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     global _lib
     _lib = None
     return LIB_PATH
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """g++ -O3 -shared: builds csrc/libq2048_host.so, the CPU twin (device "cpu")."""
+    deps = [os.path.join(CSRC, d) for d in HOST_DEPS] + [os.path.join(INCLUDE, "q2048.h")]
+    if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
+        return HOST_LIB_PATH
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise FileNotFoundError("no C++ compiler found for the host library (set CXX)")
+    cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INCLUDE, "-I", CSRC, "-o", HOST_LIB_PATH,
+           os.path.join(CSRC, "q2048_host.cpp")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    global _host_lib
+    _host_lib = None
+    return HOST_LIB_PATH
 
 
 def build_experiments(force: bool = False, verbose: bool = False) -> str:
@@ -161,6 +185,7 @@ _SIGNATURES = {
     "q2048_table_grow_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p]),
     "q2048_table_grow_finish": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "q2048_table_grow_abort": (C.c_int, [C.c_void_p]),
+    "q2048_table_trim": (C.c_int, [C.c_void_p]),
     "q2048_table_free": (C.c_int, [C.c_void_p]),
     "q2048_table_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_void_p]),
     "q2048_table_count": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -193,7 +218,7 @@ def load(path: str) -> C.CDLL:
     """Loads one build of the library and checks its ABI (every symbol, version, struct sizes)."""
     if not os.path.exists(path):
         raise ImportError(
-            f"{path} is missing: the HIP extension is required (no CPU fallback). "
+            f"{path} is missing: the native extension is required (nothing substitutes for it). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
     L = C.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
@@ -214,19 +239,42 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_host_lib = None
+
+
+def host_lib() -> C.CDLL:
+    """The CPU twin (libq2048_host.so): loaded only for the explicit device "cpu"."""
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = load(HOST_LIB_PATH)
+    return _host_lib
+
+
+def lib_for(device) -> C.CDLL:
+    """The library of a torch device: "cuda" -> the HIP library, "cpu" -> the host library.  Nothing else,
+    and never one for the other."""
+    kind = getattr(device, "type", device)
+    if kind == "cuda":
+        return lib()
+    if kind == "cpu":
+        return host_lib()
+    raise ValueError(f"no implementation for device {device!r} (cuda[:i] or cpu)")
+
+
 def use_experiments_build() -> None:
     """tools/ and tests only: route this process's calls through the measurement build."""
     global _lib
     _lib = load(build_experiments())
 
 
-def claim_timeouts() -> int:
+def claim_timeouts(L: C.CDLL | None = None) -> int:
     """Lanes that ever gave up a bounded wait in the 5x5 row-creation protocol (expected: 0)."""
     out = C.c_uint64(0)
-    check(lib().q2048_claim_timeouts(C.byref(out)), "q2048_claim_timeouts")
+    check((L or lib()).q2048_claim_timeouts(C.byref(out)), "q2048_claim_timeouts")
     return int(out.value)
 
 
 def check(code: int, what: str) -> None:
     if code != OK:
-        raise NativeError(f"{what}: {lib().q2048_strerror(code).decode()} (code {code})")
+        L = _lib or _host_lib or lib()
+        raise NativeError(f"{what}: {L.q2048_strerror(code).decode()} (code {code})")

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from .env import (BatchedGame2048Env, _ptr, _require_gpu, _Staging, _stream, raw_to_boards,
+from .env import (BatchedGame2048Env, _host_zeros, _ptr, _require_gpu, _Staging, _stream, raw_to_boards,
                   state_to_log2)
 
 
@@ -346,6 +346,8 @@ class BatchedQLearningAgent:
                  growth_step_log2: int = 2, prefetch_growth: bool = True, async_growth: bool = True,
                  verify_growth: bool = False):
         self.device = _require_gpu(device)
+        self._L = N.lib_for(self.device)
+        self.on_gpu = self.device.type == "cuda"
         if action_space != 4:
             raise ValueError("the 2048 action space has 4 actions")
         if board_size not in (4, 5):
@@ -359,17 +361,25 @@ class BatchedQLearningAgent:
         if self.growable:
             if not 0.05 <= self.load_limit <= 0.9:
                 raise ValueError("load_limit must be in [0.05, 0.9]")
-            free, _ = torch.cuda.mem_get_info(self.device)
-            share = free / _ranks_on_this_device()
+            if self.on_gpu:
+                free, _ = torch.cuda.mem_get_info(self.device)
+                share = free / _ranks_on_this_device()
+            else:                                 # the CPU twin: host memory, a quarter of what is available
+                share = 0.25 * os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+                self.async_growth = self.prefetch_growth = False    # (grows by export + import: `grow_table`)
+                if initial_capacity_log2 == "auto":
+                    initial_capacity_log2 = 22
             if initial_capacity_log2 == "auto":   # an eighth of the free memory, at most 2^30 slots (32 GiB)
                 initial_capacity_log2 = min(30, max(20, int(np.floor(np.log2(max(share / 8 / N.SIZEOF_SLOT, 2.0))))))
             capacity_log2 = int(initial_capacity_log2)
             # the largest table that fits next to its predecessor while the rows move over
             fit = int(np.floor(np.log2(max(0.9 * share / (1.5 * N.SIZEOF_SLOT), 16.0))))
             self.max_capacity_log2 = max(capacity_log2, min(int(max_capacity_log2 or 34), fit, 40))
-            placement = "chunks"                      # growth is a property of the chunk allocator
+            placement = "chunks" if self.on_gpu else "plain"   # on a GPU growth is a property of the chunk allocator
         else:
             self.max_capacity_log2 = int(capacity_log2)
+        if not self.on_gpu:
+            placement = "plain"
         if not 4 <= capacity_log2 <= 40:
             raise ValueError("capacity_log2 must be in [4, 40]")
         self.action_space = action_space                                       # :21
@@ -412,7 +422,7 @@ class BatchedQLearningAgent:
         self._row_cache = None
         # statistics mirror of the fused rollout: the launch's last block copies both vectors into pinned
         # host memory the kernels address directly (q2048_rollout_opts.stats_mirror)
-        self._mirror = torch.zeros(N.MIRROR_WORDS, dtype=torch.int64).pin_memory()
+        self._mirror = _host_zeros(N.MIRROR_WORDS, torch.int64, self.device)
         self._mirror_np = self._mirror.numpy()
         self._mirror_ticket = torch.zeros(2, dtype=torch.int32, device=self.device)
         self._mirror_launches = 0
@@ -425,7 +435,7 @@ class BatchedQLearningAgent:
             return None
         c = self._row_cache
         if c is None or c.shape[0] != B:
-            c = self._row_cache = torch.zeros((B, int(N.lib().q2048_sizeof_rowcache(self.board_size))),
+            c = self._row_cache = torch.zeros((B, int(self._L.q2048_sizeof_rowcache(self.board_size))),
                                               dtype=torch.uint8, device=self.device)
         return c
 
@@ -455,7 +465,7 @@ class BatchedQLearningAgent:
         boards = self._boards(boards)
         B = boards.shape[0]
         actions = torch.empty(B, dtype=torch.uint8, device=self.device)
-        N.check(N.lib().q2048_q_choose_cached(
+        N.check(self._L.q2048_q_choose_cached(
             _ptr(self.table), self.capacity_log2, _ptr(boards), B, self.board_size, float(self.epsilon),
             self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self.flags, _ptr(self._cache(B)), _ptr(actions),
             _ptr(self.status), _stream(self.device)), "q_choose")
@@ -470,7 +480,7 @@ class BatchedQLearningAgent:
         reward = self._vec(reward, torch.float32, B, "reward")
         done = self._vec(done, torch.uint8, B, "done")
         self._room_for(B)
-        N.check(N.lib().q2048_q_update_cached(
+        N.check(self._L.q2048_q_update_cached(
             _ptr(self.table), self.capacity_log2, _ptr(boards), _ptr(actions), _ptr(reward),
             _ptr(next_boards), _ptr(done), B, self.board_size, float(self.lr), float(self.gamma), self.env_id0,
             self.flags, _ptr(self._cache(B)), _ptr(self.stats_i), _ptr(self.status), _stream(self.device)),
@@ -486,7 +496,7 @@ class BatchedQLearningAgent:
         q = torch.empty((B, 4), dtype=torch.float32, device=self.device)
         found = torch.empty(B, dtype=torch.uint8, device=self.device) if return_found else None
         flags = self.flags | (N.FLAG_SINGLE_ENV if env_id is not None else 0)
-        N.check(N.lib().q2048_q_lookup(
+        N.check(self._L.q2048_q_lookup(
             _ptr(self.table), self.capacity_log2, _ptr(boards), B, self.board_size,
             self.env_id0 if env_id is None else int(env_id), flags, _ptr(q), _ptr(found),
             _ptr(self.status), _stream(self.device)), "q_lookup")
@@ -521,7 +531,7 @@ class BatchedQLearningAgent:
             log_count=_ptr(log.count) if log is not None else None, row_cache=_ptr(cache),
             stats_mirror=self._mirror.data_ptr() if self.stats_i is not None and self.stats_f is not None else None,
             mirror_ticket=_ptr(self._mirror_ticket))
-        N.check(N.lib().q2048_fused_rollout_opts(
+        N.check(self._L.q2048_fused_rollout_opts(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
             self.board_size, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
             self.env_id0, self.ctr & 0xFFFFFFFF,
@@ -556,7 +566,7 @@ class BatchedQLearningAgent:
             raise ValueError("env and agent do not match")
         if (env.seed, env.env_id0, env.ctr) != (self.seed, self.env_id0, self.ctr):
             raise ValueError("env and agent must share seed, env_id0 and step counter")
-        B, L = env.num_envs, N.lib()
+        B, L = env.num_envs, self._L
         need = int(L.q2048_det_workspace_bytes(B, self.capacity_log2))
         if need < 0:
             N.check(need, "det_workspace_bytes")
@@ -601,10 +611,12 @@ class BatchedQLearningAgent:
         (8 bytes, synchronising) and
           - the next table starts being mapped (`prefetch_growth`: already at construction / after each growth;
             else when the rows expected after this call pass half the load limit),
-          - the growth is committed -- the move queued between this launch and the previous one -- when the rows
-            expected after this call (measured rows per env-step x 1.25) pass `load_limit` AND the next table is
-            ready; when it is not ready yet the rollouts go on on the old table until the worst case (two rows
-            per env-step) would pass load_limit + 0.25 (at most 0.85), and only then wait for it.
+          - the growth is committed -- the move queued between this launch and the previous one -- when the next
+            table is ready AND the rows expected after this call (measured rows per env-step x 1.25) pass
+            `load_limit` (a quarter of it when the table was prefetched: its memory is committed anyway, and the
+            fewer rows there are the cheaper the move); while it is not ready the rollouts go on on the old table
+            until the worst case (two rows per env-step) would pass load_limit + 0.25 (at most 0.85), and only
+            then wait for it.
         A table at its largest capacity warns once when it passes the limit."""
         env_steps = int(env_steps)
         self._steps_launched += env_steps
@@ -613,12 +625,16 @@ class BatchedQLearningAgent:
         if self._retiring is not None and self._retiring.ready():
             self._finish_retiring()
         cap = 1 << self.capacity_log2
-        soft = self.load_limit * cap
+        soft, hard = self.load_limit * cap, min(0.85, self.load_limit + 0.25) * cap
         at_max = self.capacity_log2 >= self.max_capacity_log2
-        trigger = soft if (self._growth is not None or at_max) else 0.5 * soft
+        # the load at which this call has something to do: a prefetched table is moved into as soon as it is ready
+        # and a quarter of the limit is in use (the fewer rows, the cheaper the move; the memory is committed
+        # anyway); without prefetch the mapping begins at half the limit and the move waits for the limit
+        commit_at = (0.25 if self.prefetch_growth else 1.0) * soft
+        trigger = soft if at_max else (commit_at if self._growth is not None else min(0.5 * soft, commit_at))
         bound = self._rows_base + self._inserts_seen - self._inserts_at_base + 2 * (self._steps_unseen + env_steps)
-        if bound <= trigger:
-            self._steps_unseen += env_steps
+        if bound <= trigger or (self._growth is not None and bound <= hard and not self._growth.ready()):
+            self._steps_unseen += env_steps              # nothing to decide yet (or nothing to move into yet)
             return
         self._steps_launched -= env_steps                # (the read below must not count steps not yet queued)
         rows = self._rows_exact()
@@ -627,6 +643,7 @@ class BatchedQLearningAgent:
         while True:
             cap = 1 << self.capacity_log2
             soft, hard = self.load_limit * cap, min(0.85, self.load_limit + 0.25) * cap
+            commit_at = (0.25 if self.prefetch_growth else 1.0) * soft
             expect, worst = rows + self._row_rate * env_steps, rows + 2 * env_steps
             if self.capacity_log2 >= self.max_capacity_log2:
                 if rows > soft and not self._warned_full:
@@ -642,7 +659,7 @@ class BatchedQLearningAgent:
                 return
             if self._growth is None and (self.prefetch_growth or expect > 0.5 * soft):
                 self._begin_growth()
-            if self._growth is not None and (worst > hard or (expect > soft and self._growth.ready())):
+            if self._growth is not None and (worst > hard or (expect > commit_at and self._growth.ready())):
                 self._commit_growth(rows)
                 continue                                  # (a launch larger than the new table's room: again)
             return
@@ -686,12 +703,21 @@ class BatchedQLearningAgent:
         g, self._retiring = self._retiring, None
         moved = g.finish()
         ev = g.info.pop("events")
+        ev[1].synchronize()                               # (recorded right behind the library's own event)
         g.info.update({"rows": moved, "ms": round(ev[0].elapsed_time(ev[1]), 3)})
         self.growths.append(g.info)
         if moved != g.info["expected_rows"]:
             raise RuntimeError(f"Q-table self-check failed at the growth 2^{g.info['from_log2']} -> "
                                f"2^{g.info['to_log2']}: {moved} occupied slots moved, {g.info['expected_rows']} rows "
                                "created according to the kernels' counters")
+
+    def release_retired(self) -> None:
+        """Gives the tables that earlier growths left behind back to the device now (q2048_table_trim): the library
+        keeps them until their memory is needed, because freshly released memory makes the next mapping slow."""
+        owner = getattr(self.table, "_q2048_owner", None)
+        if owner is not None:
+            self.finish_growth()
+            N.check(self._L.q2048_table_trim(owner.ptr), "q2048_table_trim")
 
     def finish_growth(self) -> None:
         """Waits for a committed growth's move and runs its check (the end of a run, `verify_table`, tests)."""
@@ -706,12 +732,14 @@ class BatchedQLearningAgent:
         been free for a while.  Only tables made with capacity_log2="auto" can grow.  Returns the
         rows moved.  (`_room_for` uses the asynchronous begin / commit / finish form instead.)"""
         owner = getattr(self.table, "_q2048_owner", None)
-        if not self.growable or owner is None:
+        if not self.growable or (owner is None and self.on_gpu):
             raise RuntimeError('only a table made with capacity_log2="auto" can grow')
         new = self.capacity_log2 + 1 if new_capacity_log2 is None else int(new_capacity_log2)
         if not self.capacity_log2 < new <= self.max_capacity_log2:
             raise ValueError(f"cannot grow from 2^{self.capacity_log2} to 2^{new} slots "
                              f"(this table's largest capacity is 2^{self.max_capacity_log2})")
+        if not self.on_gpu:
+            return self._grow_on_host(new, _rows)
         self.finish_growth()
         if self._growth is not None:                      # a prepared table of another size: give it back
             g, self._growth = self._growth, None
@@ -734,6 +762,29 @@ class BatchedQLearningAgent:
                                f"{expected} rows created according to the kernels' counters")
         return moved
 
+    def _grow_on_host(self, new: int, _rows: int | None) -> int:
+        """The CPU twin's growth, through the ABI alone: every row exported, a larger table allocated, every row
+        imported (host memory has no chunk allocator to ask; same check: rows moved == rows created)."""
+        import time
+        expected = self._rows_exact() if _rows is None else int(_rows)
+        t0 = time.perf_counter()
+        keys, q = self.export_rows()
+        self.table = torch.zeros((1 << new, N.SIZEOF_SLOT), dtype=torch.uint8, device=self.device)
+        old, self.capacity_log2 = self.capacity_log2, new
+        self.invalidate_row_cache()
+        if len(q):
+            tk = torch.from_numpy(np.ascontiguousarray(keys).view(np.int64).reshape(len(q), -1))
+            self.import_rows_device(tk.reshape(-1) if self.board_size == 4 else tk, torch.from_numpy(q))
+        if self.check_status() & N.STATUS_TABLE_FULL:
+            raise RuntimeError("growth dropped rows (probe limit)")
+        moved = self.table_size()
+        self.growths.append({"from_log2": old, "to_log2": new, "rows": moved, "expected_rows": expected,
+                             "ms": round((time.perf_counter() - t0) * 1e3, 3), "at_step": self.ctr})
+        if moved != expected:
+            raise RuntimeError(f"Q-table self-check failed at the growth to 2^{new}: {moved} rows moved, {expected} "
+                               "rows created according to the counters")
+        return moved
+
     def verify_table(self) -> dict:
         """Run-time check that no row was lost or duplicated: the slots occupied now == the rows counted
         at the last count / import + the rows the kernels say they created since (Q2048_ST_INSERTS).  One
@@ -743,7 +794,7 @@ class BatchedQLearningAgent:
         self.finish_growth()
         expect = self._rows_exact()
         rows = self.table_size()
-        timeouts = N.claim_timeouts()
+        timeouts = N.claim_timeouts(self._L)
         if rows != expect or timeouts:
             raise RuntimeError(f"Q-table self-check failed: {rows} occupied slots, expected {expect} "
                                f"({self._rows_base} counted earlier + {expect - self._rows_base} created since); "
@@ -768,7 +819,7 @@ class BatchedQLearningAgent:
     def table_size(self) -> int:
         """len(q_table): occupied slots."""
         count = torch.zeros(1, dtype=torch.int64, device=self.device)
-        N.check(N.lib().q2048_table_count(_ptr(self.table), self.capacity_log2, _ptr(count),
+        N.check(self._L.q2048_table_count(_ptr(self.table), self.capacity_log2, _ptr(count),
                                           _stream(self.device)), "table_count")
         return int(count.item())
 
@@ -780,7 +831,7 @@ class BatchedQLearningAgent:
         keys = torch.empty((max(rows, 1), words), dtype=torch.int64, device=self.device)
         q = torch.empty((max(rows, 1), 4), dtype=torch.float32, device=self.device)
         count = torch.zeros(1, dtype=torch.int64, device=self.device)
-        N.check(N.lib().q2048_table_export(_ptr(self.table), self.capacity_log2, _ptr(keys),
+        N.check(self._L.q2048_table_export(_ptr(self.table), self.capacity_log2, _ptr(keys),
                                            _ptr(q), rows, words, _ptr(count), _stream(self.device)),
                 "table_export")
         got = min(int(count.item()), rows)
@@ -820,11 +871,11 @@ class BatchedQLearningAgent:
         sd = {"capacity_log2": self.capacity_log2, "board_size": self.board_size,
               "flags": self.flags, "ctr": self.ctr, "seed": self.seed, "env_id0": self.env_id0,
               "lr": self.lr, "gamma": self.gamma, "schedule": dict(vars(self.schedule)),
-              "stats_i": self.stats_i.cpu(), "stats_f": self.stats_f.cpu()}
+              "stats_i": self.stats_i.to("cpu", copy=True), "stats_f": self.stats_f.to("cpu", copy=True)}
         if compact:
             sd["keys"], sd["q"] = self.export_rows()
         else:
-            sd["table"] = self.table.cpu()
+            sd["table"] = self.table.to("cpu", copy=True)
         return sd
 
     def load_state_dict(self, sd: dict) -> None:
@@ -839,6 +890,7 @@ class BatchedQLearningAgent:
         self.finish_growth()
         self.invalidate_row_cache()
         self.table.zero_()
+        self._rebase_rows(0)                    # (the restored counters say nothing about this table yet)
         if "table" in sd:
             if sd["capacity_log2"] != self.capacity_log2:
                 raise ValueError("raw tables only load into the same capacity")
@@ -862,12 +914,35 @@ class BatchedQLearningAgent:
         tk = torch.from_numpy(keys.view(np.int64)).to(self.device)
         tq = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.device)
         status = torch.zeros(1, dtype=torch.int32, device=self.device)   # this call's own word: the
-        N.check(N.lib().q2048_table_import(_ptr(self.table), self.capacity_log2, _ptr(tk), _ptr(tq),  # agent's
+        N.check(self._L.q2048_table_import(_ptr(self.table), self.capacity_log2, _ptr(tk), _ptr(tq),  # agent's
                                            rows, keys.shape[1], _ptr(status),                          # is sticky
                                            _stream(self.device)), "table_import")
         if int(status.item()) & N.STATUS_TABLE_FULL:
             raise RuntimeError("table_import dropped rows (probe limit)")
         self._rebase_rows(self.table_size())
+
+    def import_rows_device(self, keys: torch.Tensor, q: torch.Tensor) -> None:
+        """q2048_table_import of rows that already live on the device: keys int64 [R] (4x4) or [R, 2] (5x5), q
+        float32 [R, 4].  No growth, no count: the caller sizes the table and calls `recount_rows()` at the end
+        (bulk loads, e.g. bench.py's pre-filled table)."""
+        words = 1 if self.board_size == 4 else 2
+        rows = int(q.shape[0])
+        if keys.dtype != torch.int64 or q.dtype != torch.float32 or keys.numel() != rows * words or q.shape != (rows, 4):
+            raise ValueError("keys must be int64 [R] / [R, 2] and q float32 [R, 4]")
+        if rows == 0:
+            return
+        keys, q = keys.to(self.device).contiguous(), q.to(self.device).contiguous()
+        self.invalidate_row_cache()
+        N.check(self._L.q2048_table_import(_ptr(self.table), self.capacity_log2, _ptr(keys), _ptr(q), rows, words,
+                                           _ptr(self.status), _stream(self.device)), "table_import")
+
+    def recount_rows(self) -> int:
+        """Counts the occupied slots (one streaming pass, synchronising) and makes that the base of the row
+        bookkeeping: after anything but this class's own methods has written rows."""
+        self.finish_growth()
+        rows = self.table_size()
+        self._rebase_rows(rows)
+        return rows
 
     # -- argument plumbing -----------------------------------------------------------------
     def _boards(self, b) -> torch.Tensor:
@@ -902,6 +977,7 @@ class BatchedRowTupleAgent:
                  exploration_rate=1.0, exploration_min=0.01, device="cuda", seed: int = 0,
                  env_id0: int = 0):
         self.device = _require_gpu(device)
+        self._L = N.lib_for(self.device)
         if action_space != 4:
             raise ValueError("the 2048 action space has 4 actions")
         self.lr, self.gamma = learning_rate, discount_factor
@@ -929,7 +1005,7 @@ class BatchedRowTupleAgent:
         boards = self._boards(boards)
         B = boards.shape[0]
         actions = torch.empty(B, dtype=torch.uint8, device=self.device)
-        N.check(N.lib().q2048_rt_choose(_ptr(self.weights), _ptr(boards), B, float(self.epsilon),
+        N.check(self._L.q2048_rt_choose(_ptr(self.weights), _ptr(boards), B, float(self.epsilon),
                                         self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, _ptr(actions),
                                         _stream(self.device)), "rt_choose")
         self.ctr += 1
@@ -942,7 +1018,7 @@ class BatchedRowTupleAgent:
         actions, reward, done = vec(actions, torch.uint8), vec(reward, torch.float32), vec(done, torch.uint8)
         if not (actions.shape == reward.shape == done.shape == (B,)):
             raise ValueError("actions / reward / done must have shape (B,)")
-        N.check(N.lib().q2048_rt_update(_ptr(self.weights), _ptr(boards), _ptr(actions), _ptr(reward),
+        N.check(self._L.q2048_rt_update(_ptr(self.weights), _ptr(boards), _ptr(actions), _ptr(reward),
                                         _ptr(next_boards), _ptr(done), B, float(self.lr),
                                         float(self.gamma), _ptr(self.status), _stream(self.device)),
                 "rt_update")
@@ -950,7 +1026,7 @@ class BatchedRowTupleAgent:
     def q_values(self, boards) -> torch.Tensor:
         boards = self._boards(boards)
         q = torch.empty((boards.shape[0], 4), dtype=torch.float32, device=self.device)
-        N.check(N.lib().q2048_rt_lookup(_ptr(self.weights), _ptr(boards), boards.shape[0], _ptr(q),
+        N.check(self._L.q2048_rt_lookup(_ptr(self.weights), _ptr(boards), boards.shape[0], _ptr(q),
                                         _stream(self.device)), "rt_lookup")
         return q
 
@@ -961,7 +1037,7 @@ class BatchedRowTupleAgent:
             raise ValueError("env profiles are supported by the hash-table agent only")
         if (env.seed, env.env_id0, env.ctr) != (self.seed, self.env_id0, self.ctr):
             raise ValueError("env and agent must share seed, env_id0 and step counter")
-        N.check(N.lib().q2048_rt_fused_rollout(
+        N.check(self._L.q2048_rt_fused_rollout(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.weights), env.num_envs, int(steps),
             float(self.epsilon), float(self.lr), float(self.gamma), self.seed, self.env_id0,
             self.ctr & 0xFFFFFFFF, _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status),
@@ -1066,7 +1142,7 @@ class _OneStateTable:
         io, b = o._io, o._b
         off = io.take(32)                                        # [0:16] state in, [16:32] row out
         state_to_log2(state, io.np[off:off + 16])
-        N.check(N.lib().q2048_q_lookup(
+        N.check(b._L.q2048_q_lookup(
             _ptr(b.table), b.capacity_log2, io.ptr + off, 1, 4, b.env_id0, b.flags | N.FLAG_SINGLE_ENV,
             io.ptr + off + 16, None, _ptr(b.status), _stream(b.device)), "q_lookup")
         row = _LazyRow(io, off + 16)
@@ -1110,7 +1186,7 @@ class QLearningAgent:
         io, b = self._io, self._b
         off = io.take(32)                                        # [0:16] state in, [16] action out
         state_to_log2(state, io.np[off:off + 16])
-        N.check(N.lib().q2048_q_choose(
+        N.check(b._L.q2048_q_choose(
             _ptr(b.table), b.capacity_log2, io.ptr + off, 1, 4, float(b.epsilon), b.seed, b.env_id0,
             b.ctr & 0xFFFFFFFF, b.flags, io.ptr + off + 16, _ptr(b.status), _stream(b.device)), "q_choose")
         b.ctr += 1
@@ -1127,7 +1203,7 @@ class QLearningAgent:
         state_to_log2(next_state, buf[off + 16:off + 32])
         buf[off + 32], buf[off + 33] = int(action), 1 if done else 0
         buf[off + 36:off + 40].view(np.float32)[0] = reward
-        N.check(N.lib().q2048_q_update(
+        N.check(b._L.q2048_q_update(
             _ptr(b.table), b.capacity_log2, io.ptr + off, io.ptr + off + 32, io.ptr + off + 36,
             io.ptr + off + 16, io.ptr + off + 33, 1, 4, float(b.lr), float(b.gamma), b.env_id0, b.flags,
             _ptr(b.stats_i), _ptr(b.status), _stream(b.device)), "q_update")

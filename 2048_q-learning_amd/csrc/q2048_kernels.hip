@@ -2464,7 +2464,7 @@ namespace {
 // (scratch: 64 B of device memory + 64 B of pinned host memory per family for the counters of a growth, and a
 // stream of its own -- allocated once, so that no growth ever calls hipMalloc / hipFree, which synchronise the device)
 struct Family { size_t chunk; int dev, cap0_log2, max_log2; u64* dev_scratch; unsigned long long* host_scratch; hipStream_t stream; };
-struct ChunkedTable { size_t bytes, chunk; int cap_log2; Family* fam; std::vector<hipMemGenericAllocationHandle_t> handles; };
+struct ChunkedTable { size_t bytes, chunk; int cap_log2; Family* fam; std::vector<hipMemGenericAllocationHandle_t> handles; bool retired = false; };
 std::mutex g_tables_mutex;
 std::map<void*, ChunkedTable> g_tables;
 std::vector<Family*> g_families;                         // kept for the life of the process
@@ -2601,11 +2601,17 @@ int map_table_with(Family* f, int cap_log2, size_t chunk, q2048_slot** out) {
   *out = reinterpret_cast<q2048_slot*>(va);
   return Q2048_OK;
 }
-// the table of a family: from at most kMaxChunks chunks if the stack will have it, else from the family's own
+int release_retired(int dev, Family* only);
+// the table of a family: from at most kMaxChunks chunks if the stack will have it, else from the family's own;
+// when the device has no room, once more after the tables that growths have retired on it were given back
 int map_table(Family* f, int cap_log2, q2048_slot** out) {
   const size_t chunk = chunk_of(*f, cap_log2);
   int rc = map_table_with(f, cap_log2, chunk, out);
   if (rc == Q2048_ERR_ALLOC && chunk != f->chunk) rc = map_table_with(f, cap_log2, f->chunk, out);
+  if (rc == Q2048_ERR_ALLOC && release_retired(f->dev, nullptr) > 0) {
+    rc = map_table_with(f, cap_log2, chunk, out);
+    if (rc == Q2048_ERR_ALLOC && chunk != f->chunk) rc = map_table_with(f, cap_log2, f->chunk, out);
+  }
   return rc;
 }
 // takes a table out of the registry and gives its chunks back (the address range stays reserved, above).
@@ -2644,6 +2650,27 @@ int unregister_and_release(q2048_slot* table, bool quiesced) {
   }
 #endif
   return release_chunks(table, t.chunk, t.handles, t.handles.size()) ? Q2048_ERR_ALLOC : Q2048_OK;
+}
+
+// RETIRED tables.  A growth that has moved its rows does not give the old table's memory back: memory released
+// by a process is wiped by the driver before it is handed out again, at ~40 GB/s, and an allocation made while that
+// goes on waits for it -- hipMemCreate of a 128 GiB table takes 30 ms on memory that has been free for a while and
+// 3-4 s right after 128 GiB were released (profiles/r05_vmm_wipe.txt), which is exactly what the NEXT growth of a
+// run would meet.  So the old table stays mapped and allocated (nothing reads or writes it; a stale pointer into it
+// hits dead memory, not a fault) until (a) a mapping on its device finds no room, (b) the last live table of its
+// family is freed, or (c) the caller asks (q2048_table_trim).  With fourfold steps the retired tables of a family
+// add up to a third of the live one.  Returns the number of tables released.
+int release_retired(int dev, Family* only) {
+  std::vector<q2048_slot*> gone;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    for (auto& kv : g_tables)
+      if (kv.second.retired && kv.second.fam->dev == dev && (only == nullptr || kv.second.fam == only))
+        gone.push_back(static_cast<q2048_slot*>(kv.first));
+  }
+  int n = 0;
+  for (q2048_slot* t : gone) n += unregister_and_release(t, n > 0) == Q2048_OK;   // one device synchronize is enough
+  return n;
 }
 
 // ONE host thread per process for the virtual-memory calls that a growth takes off the caller's critical path
@@ -2892,9 +2919,13 @@ int q2048_table_grow_finish(q2048_growth* g, int64_t* rows_moved) {
     std::lock_guard<std::mutex> lock(g_growth_mutex);
     growth_forget(g);
   }
-  // nothing on the device reads the old table any more (the event): its chunks go back from the worker thread --
-  // 16 us per chunk that the caller does not wait for.  On Q2048_ERR_VERIFY both tables stay mapped.
-  if (rc == Q2048_OK) Worker::worker().post([old_t] { (void)unregister_and_release(old_t, true); });
+  // nothing on the device reads the old table any more (the event): it is RETIRED -- kept until its memory is
+  // needed (release_retired).  On Q2048_ERR_VERIFY both tables stay live.
+  if (rc == Q2048_OK) {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    auto it = g_tables.find(old_t);
+    if (it != g_tables.end()) it->second.retired = true;
+  }
   return rc;
 }
 
@@ -2927,8 +2958,21 @@ int q2048_table_grow(q2048_slot* table, int cap_log2, int new_cap_log2, int key_
     (void)unregister_and_release(bigger, false);
     return e;
   }
-  Worker::worker().drain();                               // host-synchronous: the old table's memory is back
+  (void)unregister_and_release(table, false);             // host-synchronous form: the old table's memory is back
   *table_out = bigger;
+  return Q2048_OK;
+}
+
+int q2048_table_trim(q2048_slot* table) {
+  if (table == nullptr) return Q2048_ERR_NULL;
+  Family* f = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    auto it = g_tables.find(table);
+    if (it == g_tables.end()) return Q2048_ERR_NULL;
+    f = it->second.fam;
+  }
+  (void)release_retired(f->dev, f);
   return Q2048_OK;
 }
 
@@ -2938,20 +2982,33 @@ int q2048_table_free(q2048_slot* table) {
   // aborted, a committed one finished), so that a caller tearing down in any order frees everything once
   for (;;) {
     q2048_growth* g = nullptr;
-    bool committed = false, is_old = false;
+    bool committed = false;
     {
       std::lock_guard<std::mutex> lock(g_growth_mutex);
       g = growth_of(table);
-      if (g != nullptr) { committed = g->committed; is_old = g->old_t == table; }
+      if (g != nullptr) committed = g->committed;
     }
     if (g == nullptr) break;
-    if (!committed) { (void)q2048_table_grow_abort(g); continue; }
-    const int rc = q2048_table_grow_finish(g, nullptr);
-    Worker::worker().drain();
-    if (is_old) return rc == Q2048_OK ? Q2048_OK : unregister_and_release(table, false);   // finish released it
+    if (!committed) (void)q2048_table_grow_abort(g);
+    else (void)q2048_table_grow_finish(g, nullptr);
   }
-  Worker::worker().drain();                               // (a release of this very table may be on its way)
-  return unregister_and_release(table, false);
+  Worker::worker().drain();
+  Family* f = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    auto it = g_tables.find(table);
+    if (it == g_tables.end()) return Q2048_ERR_NULL;      // not one of q2048_table_reserve's
+    f = it->second.fam;
+  }
+  const int rc = unregister_and_release(table, false);
+  // the family's last live table is gone: its retired predecessors go with it
+  bool live = false;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    for (auto& kv : g_tables) live = live || (kv.second.fam == f && !kv.second.retired);
+  }
+  if (!live) (void)release_retired(f->dev, f);
+  return rc;
 }
 
 int q2048_table_count(const q2048_slot* table, int cap_log2, int64_t* count, void* stream) {

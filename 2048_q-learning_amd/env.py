@@ -4,8 +4,10 @@ QLearningBase/environment/Game2048_env.py (class Game2048_env, :78-205).
 `BatchedGame2048Env` keeps the reference's method names (`reset`, `step`, `action_space.n`,
 `score`) over B boards resident in HBM; `Game2048_env` is the one-env adapter that returns
 the reference's Python types so that the loop body of Agent/main.py:91-101 runs unchanged.
-All computation happens in the HIP kernels behind include/q2048.h; torch only owns the device
-memory and the stream."""
+All computation happens behind the C ABI of include/q2048.h -- the HIP kernels for device "cuda[:i]",
+their CPU twin (libq2048_host.so: the same ABI from the same per-lane arithmetic) for the explicit
+device "cpu"; torch only owns the memory and the stream.  The device is the caller's choice and is
+never substituted."""
 from __future__ import annotations
 
 import numpy as np
@@ -27,16 +29,37 @@ def _ptr(t: torch.Tensor | None):
 
 
 def _stream(device: torch.device):
-    return torch.cuda.current_stream(device).cuda_stream
+    """The caller's current stream as the ABI's `stream` argument (host library: ignored, NULL)."""
+    return torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None
+
+
+def _sync(device: torch.device) -> None:
+    """Waits for the caller's stream (host library: every call is complete when it returns)."""
+    if device.type == "cuda":
+        torch.cuda.current_stream(device).synchronize()
+
+
+def _host_zeros(shape, dtype, device: torch.device) -> torch.Tensor:
+    """Host memory the kernels can address directly: pinned (mapped into the device's address space) for a
+    GPU, plain for the host library."""
+    t = torch.zeros(shape, dtype=dtype)
+    return t.pin_memory() if device.type == "cuda" else t
 
 
 def _require_gpu(device) -> torch.device:
+    """The device a caller named, checked: "cuda[:i]" needs a visible HIP device and the HIP library, "cpu"
+    (the explicit CPU twin) the host library.  Whichever is missing raises -- nothing is substituted.
+    (The name is historical: until round 5 only GPUs passed.)"""
     device = torch.device(device)
+    if device.type == "cpu":
+        N.host_lib()
+        return device
     if device.type != "cuda":
-        raise RuntimeError("2048_q-learning_amd runs on MI355X only (device must be 'cuda[:i]'); "
-                           "there is no CPU implementation of the product path")
+        raise RuntimeError(f"2048_q-learning_amd runs on 'cuda[:i]' (MI355X) or, by explicit request, 'cpu'; "
+                           f"not on {device}")
     if not torch.cuda.is_available():
-        raise RuntimeError("no HIP device visible: the HIP extension cannot run")
+        raise RuntimeError("no HIP device visible: the HIP extension cannot run (device 'cpu' must be asked "
+                           "for by name)")
     N.lib()
     return device
 
@@ -79,6 +102,7 @@ class BatchedGame2048Env:
                     or clone.  `boards` is always one of two ping-pong buffers: the tensor returned by
                     step t is overwritten by step t + 2."""
         self.device = _require_gpu(device)
+        self._L = N.lib_for(self.device)
         self.copy_outputs = bool(copy_outputs)
         if board_size not in (4, 5):
             raise NotImplementedError("board_size must be 4 (the reference) or 5")
@@ -99,7 +123,7 @@ class BatchedGame2048Env:
 
         def alloc(shape, dtype):
             if self.host_visible:                       # pinned + mapped: same address on the device
-                return torch.zeros(shape, dtype=dtype).pin_memory()
+                return _host_zeros(shape, dtype, self.device)
             return torch.zeros(shape, dtype=dtype, device=self.device)
 
         # one buffer for the host-visible one-env adapter (its step is in place), two otherwise
@@ -111,10 +135,10 @@ class BatchedGame2048Env:
         self._max = alloc(B, torch.uint8)
         self._max_tile = alloc(B, torch.int32)
         self.status = alloc(1, torch.int32)
-        N.check(N.lib().q2048_env_init(_ptr(self.boards), _ptr(self.aux), B, self.board_size,
+        N.check(self._L.q2048_env_init(_ptr(self.boards), _ptr(self.aux), B, self.board_size,
                                        self.seed, self.env_id0, _stream(self.device)), "env_init")
         if self.host_visible:
-            torch.cuda.current_stream(self.device).synchronize()
+            _sync(self.device)
 
     @property
     def boards(self) -> torch.Tensor:
@@ -126,11 +150,11 @@ class BatchedGame2048Env:
         """Game2048_env.reset (:187-191) for the lanes where mask != 0 (all when None)."""
         if mask is not None:
             mask = self._as_u8(mask, "mask")
-        N.check(N.lib().q2048_env_reset_ex(_ptr(self.boards), _ptr(self.aux), _ptr(mask),
+        N.check(self._L.q2048_env_reset_ex(_ptr(self.boards), _ptr(self.aux), _ptr(mask),
                                            self.num_envs, self.board_size, self.seed, self.env_id0,
                                            self.env_flags, _stream(self.device)), "env_reset")
         if self.host_visible:
-            torch.cuda.current_stream(self.device).synchronize()
+            _sync(self.device)
         return self.boards
 
     def step(self, actions: torch.Tensor):
@@ -140,7 +164,7 @@ class BatchedGame2048Env:
         actions = self._as_u8(actions, "actions")
         src = self._bufs[self._cur]
         nxt = (self._cur + 1) % len(self._bufs)
-        N.check(N.lib().q2048_env_step_to(
+        N.check(self._L.q2048_env_step_to(
             _ptr(src), _ptr(self._bufs[nxt]), _ptr(self.aux), _ptr(actions), self.num_envs, self.board_size,
             self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self.env_flags, _ptr(self._reward),
             _ptr(self._done), _ptr(self._max), _ptr(self._max_tile), _ptr(self.status),
@@ -148,7 +172,7 @@ class BatchedGame2048Env:
         self._cur = nxt
         self.ctr += 1
         if self.host_visible:                           # host tensors: the launch has to finish first
-            torch.cuda.current_stream(self.device).synchronize()
+            _sync(self.device)
         if self.copy_outputs:
             return self.boards, self._reward.clone(), self._done.view(torch.bool).clone(), self._max_tile.clone()
         return self.boards, self._reward, self._done.view(torch.bool), self._max_tile
@@ -167,7 +191,7 @@ class BatchedGame2048Env:
         """uint8 [B]: bit a set iff action a would change the board -- the trial-move loop of
         Deep_QLearning/main_dir/mainDQL_CNN_step2.py:168-174."""
         mask = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
-        N.check(N.lib().q2048_legal_moves(_ptr(self.boards), self.num_envs, self.board_size,
+        N.check(self._L.q2048_legal_moves(_ptr(self.boards), self.num_envs, self.board_size,
                                           _ptr(mask), _stream(self.device)), "legal_moves")
         return mask
 
@@ -178,7 +202,7 @@ class BatchedGame2048Env:
         if dtype not in (torch.float32, torch.bfloat16):
             raise TypeError("dtype must be float32 or bfloat16")
         out = torch.empty((self.num_envs, 16, 4, 4), dtype=dtype, device=self.device)
-        N.check(N.lib().q2048_encode_onehot(_ptr(self.boards), self.num_envs,
+        N.check(self._L.q2048_encode_onehot(_ptr(self.boards), self.num_envs,
                                             0 if dtype == torch.float32 else 1, _ptr(out),
                                             _stream(self.device)), "encode_onehot")
         return out
@@ -186,7 +210,7 @@ class BatchedGame2048Env:
     # -- checkpoint ---------------------------------------------------------------------------
     def state_dict(self) -> dict:
         """Everything needed to continue this batch bit-exactly (host tensors)."""
-        return {"boards": self.boards.cpu(), "aux": self.aux.cpu(), "ctr": self.ctr,
+        return {"boards": self.boards.to("cpu", copy=True), "aux": self.aux.to("cpu", copy=True), "ctr": self.ctr,
                 "seed": self.seed, "env_id0": self.env_id0, "board_size": self.board_size,
                 "profile": self.profile, "reset_shaping_state": self.reset_shaping_state}
 
@@ -209,7 +233,7 @@ class BatchedGame2048Env:
     def check_status(self) -> int:
         """Synchronising read of the device status word; raises on a rejected action."""
         if self.host_visible:
-            torch.cuda.current_stream(self.device).synchronize()
+            _sync(self.device)
         s = int(self.status.item())
         if s & N.STATUS_BAD_ACTION:
             self.status.zero_()
@@ -225,7 +249,10 @@ class BatchedGame2048Env:
             if t.numel() and (int(t.min()) < 0 or int(t.max()) > 255):
                 raise ValueError(f"{name} out of range")
             t = t.to(torch.uint8)
-        t = (t.cpu().pin_memory() if self.host_visible else t.to(self.device)).contiguous()
+        if self.host_visible and self.device.type == "cuda":
+            t = t.cpu().pin_memory().contiguous()
+        else:
+            t = t.to(self.device).contiguous()
         if t.shape != (self.num_envs,):
             raise ValueError(f"{name} must have shape ({self.num_envs},), got {tuple(t.shape)}")
         return t
@@ -295,7 +322,7 @@ class _Staging:
 
     def __init__(self, device: torch.device, nbytes: int = 1 << 14):
         self.device = device
-        self.host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        self.host = _host_zeros(nbytes, torch.uint8, device)
         self.np = self.host.numpy()
         self.ptr = self.host.data_ptr()
         self.pos = 0
@@ -310,7 +337,7 @@ class _Staging:
         return off
 
     def sync(self) -> None:
-        torch.cuda.current_stream(self.device).synchronize()
+        _sync(self.device)
         pending, self.pending = self.pending, []
         for ref in pending:
             obj = ref()
@@ -325,19 +352,30 @@ class Game2048_env:
     one kernel launch and one stream synchronisation."""
 
     def __init__(self, device="cuda", seed: int = 0, env_id: int = 0, profile: str = "shaped",
-                 reset_shaping_state: bool = False):
+                 reset_shaping_state: bool = False, play_first_board: bool = False):
+        """play_first_board  the reset() that the loop makes before its FIRST episode (Agent/main.py:81) returns
+                    the constructor's game instead of drawing another one.  The reference throws that first game
+                    away unplayed (a second pair of spawns, statistically the same board); with this flag the
+                    one-env loop plays exactly what lane 0 of the batched rollout plays -- and what the golden
+                    transcript G6 recorded from the reference -- draw for draw.  Default off: the reference's
+                    call sequence."""
+        self._keep_first = bool(play_first_board)
         self._b = BatchedGame2048Env(1, 4, device, seed, env_id, profile=profile,
                                      reset_shaping_state=reset_shaping_state, host_visible=True)
         self.action_space = self._b.action_space
         self.game = _Game(self)
         b = self._b
-        self._acts = torch.arange(4, dtype=torch.uint8).pin_memory()
+        self._acts = _host_zeros(4, torch.uint8, b.device)
+        self._acts.copy_(torch.arange(4, dtype=torch.uint8))
         self._board_np = b.boards.numpy().reshape(16)
         self._reward_np, self._done_np, self._max_np = b._reward.numpy(), b._done.numpy(), b._max.numpy()
         self._args = (b.boards.data_ptr(), b.aux.data_ptr())
         self._outs = (b._reward.data_ptr(), b._done.data_ptr(), b._max.data_ptr(), b.status.data_ptr())
 
     def reset(self) -> np.ndarray:
+        if self._keep_first:                                         # the constructor's game is the first episode
+            self._keep_first = False
+            return boards_to_raw(self._board_np)
         self._b.reset()                                              # synchronises
         return boards_to_raw(self._board_np)
 
@@ -346,12 +384,13 @@ class Game2048_env:
         if not 0 <= action <= 3:
             raise ValueError(f"action {action} outside 0..3")
         b = self._b
-        N.check(N.lib().q2048_env_step_ex(
+        self._keep_first = False
+        N.check(b._L.q2048_env_step_ex(
             self._args[0], self._args[1], self._acts.data_ptr() + action, 1, 4, b.seed, b.env_id0,
             b.ctr & 0xFFFFFFFF, b.env_flags, None, self._outs[0], self._outs[1], self._outs[2],
             self._outs[3], _stream(b.device)), "env_step")
         b.ctr += 1
-        torch.cuda.current_stream(b.device).synchronize()
+        _sync(b.device)
         return (boards_to_raw(self._board_np), float(self._reward_np[0]), bool(self._done_np[0]),
                 1 << int(self._max_np[0]))
 

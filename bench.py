@@ -33,12 +33,15 @@ Extra objects on the line:
   roofline      HBM roofline of the dominant kernel (k_fused_rollout): algorithmic bytes per
                 launch (122 B per env-step) / average launch duration measured
                 with HIP events on the launching stream, against the 8 TB/s HBM3E peak; `traffic`
-                only when the committed PMC passes were taken with this run's configuration.
+                (and `fabric_frac` = traffic / launch time / peak: how busy the memory system is, next to
+                `frac`, how well it is used, and `physical_minimum`, the run's own useful bytes) only when
+                the committed PMC passes were taken with this run's configuration on these kernel sources.
   cpu_baseline  the CPU oracle (a C port of the reference loop, oracle/) timed on this host's
                 cores on a bounded sample of the same workload (rank 0, after the GPU regions, at
                 every N): all cores and one thread, with the CPU model.
-  companions    the same protocol at SURVEY 8(d)'s 2^28-slot table, at eps = 0.01 and on 5x5 boards
-                (N = 1 only).
+  companions    the same protocol at SURVEY 8(d)'s 2^28-slot table, at eps = 0.01, on 5x5 boards and on a table
+                pre-filled (untimed) to load 0.45 -- the steady state of a long run; the main line's table is
+                young (N = 1 only).
 
 `--check-shards` is a different job (no timing): every rank plays K steps of its shard at eps = 1
 and rank 0 prints 64-bit hashes of boards + aux per 4096 global env ids -- equal lists for N = 1
@@ -69,7 +72,8 @@ ALGO_BYTES_FUSED_5X5 = 156
 ALGO_BYTES_ROW_TUPLE = 64 + 8 * 16 + 4 * 4 + 6
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
-PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r04_pmc_traffic.json", "r04_pmc_traffic_k20.json")]
+STEADY_LOAD = 0.45          # the pre-filled companion's table load (a growing table's limit is 0.5)
+PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r05_pmc_traffic.json", "r05_pmc_traffic_k20.json")]
 CSRC = os.path.join(REPO, "2048_q-learning_amd", "csrc")
 KERNEL_SOURCES = ("q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc")
 
@@ -140,7 +144,7 @@ def load_launcher():
 
 def committed_pmc_traffic(cfg: dict):
     """(bytes per env-step, source, None) when one of the committed rocprofv3 PMC profiles
-    (profiles/r04_pmc_traffic*.json: the SURVEY protocol's 64-step launches, the driver's single
+    (profiles/r05_pmc_traffic*.json: the SURVEY protocol's 64-step launches, the driver's single
     20-step launch) was taken with this run's configuration AND on these kernel sources
     (`kernel_sources_sha16`, written by tools/pmc_summary.py on the box that ran the passes), else
     (None, None, what the committed passes were taken with)."""
@@ -214,8 +218,33 @@ def cpu_baseline(args, seconds: float) -> dict:
             "reference_python_1core_survey_container": 11144.0}
 
 
+def prefill(torch, agent, load: float, seed: int) -> int:
+    """Untimed: pseudo-random rows (keys that are no state of any game in this run, zero values) imported until
+    the table holds `load` x its capacity -- the table of a run that has been going on for a while, where a
+    growing table (capacity_log2="auto") spends its life: between a quarter of its load limit and the limit."""
+    gen = torch.Generator(device=agent.device)
+    gen.manual_seed(0x2048 + seed)
+    want, chunk = int(load * (1 << agent.capacity_log2)), 1 << 25
+    zeros = torch.zeros((chunk, 4), dtype=torch.float32, device=agent.device)
+    words = 1 if agent.board_size == 4 else 2
+    while want > 0:
+        n = min(chunk, want)
+        keys = torch.randint(-(1 << 62), 1 << 62, (n, words), dtype=torch.int64, device=agent.device, generator=gen)
+        keys |= (-(1 << 63)) if words == 2 else 1        # 5x5 key words carry bit 63; a 4x4 key is never 0
+        agent.import_rows_device(keys.view(-1) if words == 1 else keys, zeros[:n])
+        want -= n
+    del zeros
+    if agent.check_status() & pkg_status_full():
+        raise SystemExit("prefill: the table dropped rows")
+    return agent.recount_rows()
+
+
+def pkg_status_full() -> int:
+    return 4   # Q2048_STATUS_TABLE_FULL
+
+
 def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, steps, warmup, repeats,
-            S, reducer, board_size=None):
+            S, reducer, board_size=None, prefill_load=0.0):
     """The protocol of the module docstring for one configuration.  Returns a dict of raw
     measurements (region times are MAX over ranks)."""
     board_size = args.board_size if board_size is None else board_size
@@ -236,6 +265,7 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
                                           placement=placement, row_cache=not args.no_row_cache)
         synth = agent
         agent.experiment_bits = args.experiment_bits
+    prefilled_rows = prefill(torch, agent, prefill_load, args.seed) if prefill_load > 0 else 0
 
     def run(steps_):
         launches, left = 0, steps_
@@ -310,7 +340,8 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
     del agent, synth, env
     torch.cuda.empty_cache()
     return {"regions": regions, "table_rows": table_rows, "status": status, "mirrored": mirrored,
-            "placement": placement_report, "prep_episodes_per_env": prep_episodes_per_env}
+            "placement": placement_report, "prep_episodes_per_env": prep_episodes_per_env,
+            "prefilled_rows": prefilled_rows}
 
 
 def summarise(m, shard, steps, algo_bytes):
@@ -398,6 +429,10 @@ def run_rank(args):
             roofline["traffic"] = per_step * shard.num_envs * (args.steps / s["launches"])
             roofline["traffic_bytes_per_env_step"] = per_step
             roofline["traffic_source"] = source
+            # what the memory fabric actually carried per second of this launch, against the peak: `frac` prices
+            # the algorithm's bytes, this one the requests the kernel really issued (128-B read granules, 32-B
+            # write-backs, 64-B atomics) -- how busy the memory system is, as opposed to how well it is used
+            roofline["fabric_frac"] = roofline["traffic"] / s["avg_launch_s"] / 1e9 / HBM_PEAK_GBS
         elif other is not None:
             roofline["traffic_profile_config"] = other   # the committed passes are for another run
 
@@ -447,12 +482,18 @@ def run_rank(args):
         # runs on one box, round 4: 63.0 / 65.4 / 65.2 us per step on 2^30 slots in chunks against 65.0 / 64.5 /
         # 64.9 on 2^32 -- profiles/r04_5x5_capacity_ab.txt -- so it runs on the main line's table size)
         cap5 = cap_log2
-        for name, c_eps, c_cap, c_n in (("capacity 2^28 (SURVEY 8(d))", args.eps, 28, args.board_size),
-                                        ("epsilon 0.01 (argmax path)", 0.01, cap_log2, args.board_size),
-                                        ("5x5 boards (BASELINE configs[4])", args.eps, cap5, 5)):
+        for name, c_eps, c_cap, c_n, c_fill in (
+                ("capacity 2^28 (SURVEY 8(d))", args.eps, 28, args.board_size, 0.0),
+                ("epsilon 0.01 (argmax path)", 0.01, cap_log2, args.board_size, 0.0),
+                ("5x5 boards (BASELINE configs[4])", args.eps, cap5, 5, 0.0),
+                # the main line runs on a YOUNG table (load < 0.1 at the driver's K = 20): this is the same workload
+                # on the table of a run that has been going on for a while -- pre-filled (untimed) to load
+                # STEADY_LOAD, where a growing table spends the end of every growth cycle
+                (f"steady state: table pre-filled to load {STEADY_LOAD}", args.eps, cap_log2, args.board_size, STEADY_LOAD)):
             if c_n == args.board_size and name.startswith("5x5"):
                 continue
-            budget = int(0.5 * (1 << c_cap) / (0.75 * B))          # learning steps the table can take
+            # learning steps the table can take: up to load 0.5; a pre-filled one at most 0.05 beyond its fill
+            budget = int((0.05 if c_fill else 0.5) * (1 << c_cap) / (0.75 * B))
             c_rep = 3
             c_steps = max(1, min(args.steps, budget // (c_rep + 1)))
             c_warm = max(1, min(args.warmup, budget - c_rep * c_steps))
@@ -460,7 +501,7 @@ def run_rank(args):
             c_bytes = ALGO_BYTES_FUSED_4X4 if c_n == 4 else ALGO_BYTES_FUSED_5X5
             cm = measure(pkg, torch, args, dev, shard, world, eps=c_eps, cap_log2=c_cap,
                          placement=args.placement, steps=c_steps, warmup=c_warm, repeats=c_rep, S=c_S,
-                         reducer=reducer, board_size=c_n)
+                         reducer=reducer, board_size=c_n, prefill_load=c_fill)
             cs = summarise(cm, shard, c_steps, c_bytes)
             cst = cs["median_region"]["stats"]
             comps.append({"name": name, "epsilon": c_eps, "table_capacity_log2": c_cap, "board_size": c_n,
@@ -471,6 +512,7 @@ def run_rank(args):
                           "roofline_frac": cs["achieved_gbs"] / HBM_PEAK_GBS,
                           "inserts_per_step": cst["inserts"] / max(cst["steps"], 1),
                           "episodes": cst["episodes"], "table_placement": cm["placement"],
+                          "prefilled_rows": cm["prefilled_rows"],
                           "table_load_factor": cm["table_rows"] / float(1 << c_cap)})
         out["companions"] = comps
 

@@ -408,14 +408,18 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  *       streaming pass, 21 ms per 128 GiB).  On error the old table is intact and still the caller's, g is gone.
  *   q2048_table_grow_finish(g, &rows)   waits for the move, checks it -- every occupied slot of the old table found
  *       its place (and, with VERIFY_COUNT, the new table holds exactly that many rows): Q2048_ERR_VERIFY otherwise,
- *       both tables then stay mapped -- and hands the old table to the host thread for release (16 us per chunk
- *       the caller does not wait for).  The old table must not be touched after a successful finish.  rows (host
- *       int64, may be NULL) = rows moved = the occupied slots of the old table: compare it with the rows the
- *       kernels reported (Q2048_ST_INSERTS) and the old table is verified end to end.
+ *       both tables then stay live -- and RETIRES the old table: it is the library's from here on (do not free or
+ *       touch it) and its memory is kept until a mapping on the device finds no room, the family's last live table
+ *       is freed, or q2048_table_trim(live table) asks for it -- because memory a process releases is wiped by the
+ *       driver at ~40 GB/s before it is handed out again, and the next mapping would wait for that: hipMemCreate of
+ *       128 GiB takes 30 ms on memory that has been free for a while and 3-4 s right after 128 GiB were released,
+ *       by this or by the previous process (profiles/r05_vmm_wipe.txt).  rows (host int64, may be NULL) = rows
+ *       moved = the occupied slots of the old table: compare it with the rows the kernels reported
+ *       (Q2048_ST_INSERTS) and the old table is verified end to end.
  *   q2048_table_grow_abort(g)     before the commit: the prepared table is released, the old one untouched.
  * One growth per table at a time (Q2048_ERR_BUSY); the next growth of the NEW table may begin right after the
  * commit, its commit only after the previous finish.  q2048_table_grow(...) is begin + commit(VERIFY_COUNT) +
- * finish + wait for the release in one host-synchronous call.  While both tables exist the device holds both.
+ * finish + the release of the old table in one host-synchronous call.  While both tables exist the device holds both.
  *
  * Chunk sizes: a table of a family that can grow is cut into as few chunks as 32 MiB allows (2 MiB up to 2 GiB,
  * bytes / 1024 up to 32 GiB, 32 MiB beyond: 4096 chunks for 128 GiB).  hipMemMap / hipMemUnmap / hipMemSetAccess
@@ -423,8 +427,9 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  * profiles/r04_growth_phases_2MiB_chunks.txt); what hipMemCreate costs depends on the state of the device's free
  * memory, not on the chunk: 4-30 us per chunk on memory that has been free for a while, seconds per table (at any
  * chunk size from 8 MiB to 1 GiB) when the driver hands out memory that was released moments before, by this or
- * by the previous process (profiles/r05_vmm_cost_by_chunk.txt, r05_vmm_cost_small_chunks.txt) -- which is what
- * round 4's 1.9 s for the step to 128 GiB was.  q2048_table_alloc keeps the chunk size it is asked for.
+ * by the previous process, and is still being wiped (profiles/r05_vmm_cost_by_chunk.txt,
+ * r05_vmm_cost_small_chunks.txt, r05_vmm_wipe.txt: 3.2-3.9 s right after, 30 ms twelve seconds later) -- which is
+ * what round 4's 1.9 s for the step to 128 GiB was.  q2048_table_alloc keeps the chunk size it is asked for.
  * The caller decides when to grow: between launches, when rows created / capacity passes its load limit (the
  * rollout's step slows from 46.7 to 66.3 us as the load goes from 0.12 to 0.54, profiles/r03_load_curve.jsonl).
  *
@@ -450,6 +455,7 @@ int q2048_table_grow_finish(q2048_growth *growth, int64_t *rows_moved);
 int q2048_table_grow_abort(q2048_growth *growth);
 int q2048_table_grow(q2048_slot *table, int cap_log2, int new_cap_log2, int key_words,
                      q2048_slot **table_out, int64_t *rows_moved, void *stream);
+int q2048_table_trim(q2048_slot *table); /* releases the retired predecessors of this table's family now */
 int q2048_table_free(q2048_slot *table);
 
 /* Placement probe (no reference counterpart): `lanes` lanes each issue `steps` scattered

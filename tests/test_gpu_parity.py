@@ -21,7 +21,18 @@ from conftest import GOLDEN, load_npz
 
 pytestmark = pytest.mark.gpu
 
-DEV = "cuda:0"
+DEV = "cuda:0"      # tests/test_host_twin.py loads this file a second time with DEV = "cpu" (the CPU twin,
+                    # libq2048_host.so) and runs the tests it lists there -- in the CPU suite, without a GPU
+
+
+def LIB(pkg):
+    """The native library of the device under test."""
+    return pkg._native.lib_for(torch.device(DEV))
+
+
+def sync():
+    if DEV != "cpu":
+        torch.cuda.synchronize()
 
 
 def release_cached_device_memory():
@@ -30,7 +41,8 @@ def release_cached_device_memory():
     import gc
 
     gc.collect()
-    torch.cuda.empty_cache()
+    if DEV != "cpu":
+        torch.cuda.empty_cache()
 
 
 def ulp32(x):
@@ -69,7 +81,7 @@ def t8(a):
 # env
 # ---------------------------------------------------------------------------------------------
 def test_native_library_is_loaded(pkg):
-    lib = pkg._native.lib()
+    lib = LIB(pkg)
     assert lib.q2048_abi_version() == pkg._native.ABI_VERSION
     assert os.path.samefile(pkg._native.LIB_PATH, os.path.join(os.path.dirname(pkg.__file__),
                                                                 "csrc", "libq2048_hip.so"))
@@ -94,11 +106,11 @@ def _step_draws(pkg, boards, aux, actions, dpos, dval):
     m = torch.empty(n, dtype=torch.uint8, device=DEV)
     st = torch.zeros(1, dtype=torch.int32, device=DEV)
     N = pkg._native
-    N.check(N.lib().q2048_env_step_draws(tb.data_ptr(), ta.data_ptr(), act.data_ptr(),
+    N.check(LIB(pkg).q2048_env_step_draws(tb.data_ptr(), ta.data_ptr(), act.data_ptr(),
                                          dp32.data_ptr(), dv32.data_ptr(), n, 4, r.data_ptr(),
                                          d.data_ptr(), m.data_ptr(), st.data_ptr(), None),
             "env_step_draws")
-    torch.cuda.synchronize()
+    sync()
     return (tb.cpu().numpy(), ta.cpu().numpy().view(pkg.AUX_DTYPE).reshape(-1), r.cpu().numpy(),
             d.cpu().numpy(), m.cpu().numpy(), int(st.item()))
 
@@ -206,7 +218,7 @@ def test_bad_action_is_rejected_not_masked(pkg):
 
 def test_abi_argument_errors(pkg):
     N = pkg._native
-    L = N.lib()
+    L = LIB(pkg)
     b = torch.zeros((4, 16), dtype=torch.uint8, device=DEV)
     a = torch.zeros((4, 16), dtype=torch.uint8, device=DEV)
     assert L.q2048_env_init(None, a.data_ptr(), 4, 4, 0, 0, None) == -1
@@ -217,8 +229,8 @@ def test_abi_argument_errors(pkg):
     assert b"NULL" in L.q2048_strerror(-1)
     with pytest.raises(NotImplementedError):
         pkg.BatchedGame2048Env(4, board_size=6, device=DEV)
-    with pytest.raises(RuntimeError):
-        pkg.BatchedGame2048Env(4, device="cpu")
+    with pytest.raises(RuntimeError):                    # "cuda[:i]" or, by explicit request, "cpu": nothing else
+        pkg.BatchedGame2048Env(4, device="meta")
     # a batch whose grid would not fit HIP's 32-bit grid.x is a size error, not a truncated launch
     too_big = (2 ** 31 - 1) * 256 + 1
     assert L.q2048_env_init(b.data_ptr(), a.data_ptr(), too_big, 4, 0, 0, None) == -2
@@ -250,14 +262,14 @@ def test_flag_bits_outside_the_abi_are_refused(pkg):
             agent.deterministic_rollout(env, 1)
     agent.flags = 0
     a = torch.zeros(64, dtype=torch.uint8, device=DEV)
-    assert N.lib().q2048_q_choose(agent.table.data_ptr(), 12, env.boards.data_ptr(), 64, 4, 0.5, 1, 0, 0, 1 << 9,
+    assert LIB(pkg).q2048_q_choose(agent.table.data_ptr(), 12, env.boards.data_ptr(), 64, 4, 0.5, 1, 0, 0, 1 << 9,
                                   a.data_ptr(), agent.status.data_ptr(), None) == -7
     assert torch.equal(env.boards, before) and agent.table_size() == 0 and env.ctr == 0 == agent.ctr
     # ... and the measurement build of the same sources takes them
     X = N.load(N.build_experiments())
     assert X.q2048_q_choose(agent.table.data_ptr(), 12, env.boards.data_ptr(), 64, 4, 0.5, 1, 0, 0, 1 << 9,
                             a.data_ptr(), agent.status.data_ptr(), None) == 0
-    torch.cuda.synchronize()
+    sync()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -278,10 +290,10 @@ def test_golden_g8_dqn_env_on_device(pkg):
     d = torch.empty(n, dtype=torch.uint8, device=DEV)
     m = torch.empty(n, dtype=torch.uint8, device=DEV)
     st = torch.zeros(1, dtype=torch.int32, device=DEV)
-    N.check(N.lib().q2048_env_step_ex(tb.data_ptr(), ta.data_ptr(), t8(g["actions"]).data_ptr(), n, 4,
+    N.check(LIB(pkg).q2048_env_step_ex(tb.data_ptr(), ta.data_ptr(), t8(g["actions"]).data_ptr(), n, 4,
                                       0, 0, 0, N.FLAG_ENV_DQN, d4.data_ptr(), r.data_ptr(),
                                       d.data_ptr(), m.data_ptr(), st.data_ptr(), None), "env_step_ex")
-    torch.cuda.synchronize()
+    sync()
     assert int(st.item()) == 0
     assert np.array_equal(tb.cpu().numpy(), g["boards_out"])
     assert np.array_equal(r.cpu().numpy().astype(np.float64), g["reward"])   # scores and -10: exact
@@ -408,7 +420,7 @@ def test_golden_g5_choose_on_device(pkg):
         x0 = torch.from_numpy(np.array([c["x0"] for c in cs], np.uint32).view(np.int32)).to(DEV)
         x1 = torch.from_numpy(np.array([c["x1"] for c in cs], np.uint32).view(np.int32)).to(DEV)
         acts = torch.empty(n, dtype=torch.uint8, device=DEV)
-        N.check(N.lib().q2048_q_choose_draws(agent.table.data_ptr(), agent.capacity_log2,
+        N.check(LIB(pkg).q2048_q_choose_draws(agent.table.data_ptr(), agent.capacity_log2,
                                              boards.data_ptr(), x0.data_ptr(), x1.data_ptr(), n, 4,
                                              float(eps), 0, 0, acts.data_ptr(),
                                              agent.status.data_ptr(), None), "q_choose_draws")
@@ -642,7 +654,7 @@ def test_fused_rollout_row_cache_and_statistics_mirror(pkg, O, n):
         while left > 0:
             s_ = min(pattern[k % len(pattern)], left)
             a.fused_rollout(e, s_)
-            torch.cuda.synchronize()
+            sync()
             mi, mf = a.mirrored_stats()                                             # (c)
             assert np.array_equal(mi, a.stats_i.cpu().numpy()) and np.array_equal(mf, a.stats_f.cpu().numpy())
             left -= s_; k += 1
@@ -685,12 +697,12 @@ def test_fused_rollout_row_cache_and_statistics_mirror(pkg, O, n):
     assert np.array_equal(outs[0][2][0], outs[1][2][0]) and np.array_equal(outs[0][2][1], outs[1][2][1])
     assert outs[0][3] == outs[1][3] == outs[0][4]
     # (c) a stale mirror is refused
-    e, a = mk(True); a.fused_rollout(e, 3); torch.cuda.synchronize(); a.mirrored_stats()
+    e, a = mk(True); a.fused_rollout(e, 3); sync(); a.mirrored_stats()
     a._mirror_launches += 1
     with pytest.raises(RuntimeError):
         a.mirrored_stats()
     # (d) the opts struct: another layout, a mirror without its ticket or without both vectors, alignment
-    L, Nn = pkg._native.lib(), pkg._native
+    L, Nn = LIB(pkg), pkg._native
     e, a = mk(True)
 
     def call(opts, stats_f=True):
@@ -707,7 +719,7 @@ def test_fused_rollout_row_cache_and_statistics_mirror(pkg, O, n):
     assert call(Nn.RolloutOpts(row_cache=a._cache(B).data_ptr() + 8)) == -3
     assert call(Nn.RolloutOpts(stats_mirror=a._mirror.data_ptr() + 4, mirror_ticket=a._mirror_ticket.data_ptr())) == -3
     assert call(None) == 0 and call(Nn.RolloutOpts()) == 0
-    torch.cuda.synchronize()
+    sync()
 
 
 @pytest.mark.parametrize("n", [4, 5])
@@ -771,7 +783,7 @@ def test_four_call_loop_without_copies_and_row_cache(pkg, O, n):
 def test_env_step_to_two_buffers(pkg):
     """q2048_env_step_to: in place == two buffers; the input buffer is untouched; a rejected action
     copies its board; overlapping buffers are refused; max_tile is the raw tile of max_log2."""
-    N, L = pkg._native, pkg._native.lib()
+    N, L = pkg._native, LIB(pkg)
     B, seed = 1000, 9
     env = pkg.BatchedGame2048Env(B, seed=seed, device=DEV)
     agent = pkg.BatchedQLearningAgent(10, exploration_rate=1.0, capacity_log2=4, seed=seed, device=DEV)
@@ -788,7 +800,7 @@ def test_env_step_to_two_buffers(pkg):
         st = torch.zeros(1, dtype=torch.int32, device=DEV)
         assert L.q2048_env_step_to(bi.data_ptr(), bo.data_ptr(), aux.data_ptr(), acts.data_ptr(), B, 4, seed, 0, 60,
                                    0, r.data_ptr(), d.data_ptr(), m.data_ptr(), mt.data_ptr(), st.data_ptr(), None) == 0
-        torch.cuda.synchronize()
+        sync()
         if two:
             assert torch.equal(bi, b0)
         assert int(st.item()) == N.STATUS_BAD_ACTION and torch.equal(bo[7], b0[7])
@@ -810,7 +822,7 @@ def test_bucketised_probing_at_high_load(pkg, n, load):
     probe limit is 2^14 slots or the whole table, not round 3's 256 -- at which a racing import at load
     0.93 dropped rows and the case was taken out of this test), every one found again with its own
     values, none twice, absent keys absent."""
-    N, L = pkg._native, pkg._native.lib()
+    N, L = pkg._native, LIB(pkg)
     cap_log2 = 14
     rows = int(load * (1 << cap_log2))
     rng = np.random.default_rng(7)
@@ -1553,7 +1565,7 @@ def test_steps_counter_and_argument_checks(pkg):
     with pytest.raises(ValueError):
         agent.q_values(torch.zeros((4, 25), dtype=torch.uint8, device=DEV))
     with pytest.raises(pkg.NativeError):
-        pkg._native.check(pkg._native.lib().q2048_fused_rollout(
+        pkg._native.check(LIB(pkg).q2048_fused_rollout(
             env.boards.data_ptr(), env.aux.data_ptr(), agent.table.data_ptr(), agent.capacity_log2, 8, 4,
             -1, 0.5, 0.1, 0.9, 0, 0, 0, 0, None, None, agent.status.data_ptr(), None), "neg steps")
 
@@ -1782,10 +1794,10 @@ def test_table_probe_leaves_a_live_table_untouched(pkg, n):
     agent.fused_rollout(env, 10)
     assert agent.table_size() > 4096
     before = agent.table.clone()
-    L = pkg._native.lib()
+    L = LIB(pkg)
     for seed in (0, 1):
         assert L.q2048_table_probe(agent.table.data_ptr(), 16, 1 << 16, 8, seed, None) == 0
-    torch.cuda.synchronize()
+    sync()
     assert torch.equal(agent.table, before)
     assert L.q2048_table_probe(None, 16, 8, 8, 0, None) == -1
     assert L.q2048_table_probe(agent.table.data_ptr(), 16, -1, 8, 0, None) == -2
@@ -1829,18 +1841,18 @@ def test_table_placements_give_the_same_learner(pkg):
     # "auto": a 1 GiB table comes in chunks (a 64 MiB one plain); of its four candidates only the winner is
     # still mapped when place_table returns, and its memory goes back when the tensor does
     import gc
-    torch.cuda.synchronize()
+    sync()
     before = torch.cuda.mem_get_info(torch.device(DEV))[0]
     t, rep = pkg.place_table(25, torch.device(DEV))
     assert rep["mode"] == "chunks" and rep["candidates"] == 4 and t.shape == (1 << 25, 32) and int(t[::4097].max()) == 0
-    torch.cuda.synchronize()
+    sync()
     held = before - torch.cuda.mem_get_info(torch.device(DEV))[0]
     assert (1 << 30) <= held < (1 << 30) + (256 << 20), held                        # the three losers were released
     del t
     gc.collect()
-    torch.cuda.synchronize()
+    sync()
     assert before - torch.cuda.mem_get_info(torch.device(DEV))[0] < (128 << 20)
-    L = pkg._native.lib()
+    L = LIB(pkg)
     out = C.c_void_p()
     assert L.q2048_table_alloc(3, 0, C.byref(out)) == -2 and L.q2048_table_alloc(20, 12345, C.byref(out)) == -2
     assert L.q2048_table_alloc(20, 0, None) == -1 and L.q2048_table_free(None) == 0
@@ -1947,7 +1959,7 @@ def test_table_grows_like_the_reference_defaultdict(pkg, n):
     assert a1.check_status() == 0 and pkg._native.claim_timeouts() == 0
     print(f"[grow {n}x{n}] async {a1.growths}\n  sync {a3.growths}\n  fourfold, no prefetch, counted {a4.growths}")
     # the C entry points of the asynchronous growth: one growth per table, abort gives the prepared table back
-    L = pkg._native.lib()
+    L = LIB(pkg)
     own, g1, g2, out = a4.table._q2048_owner, C.c_void_p(), C.c_void_p(), C.c_void_p()
     if a4._growth is not None:
         a4._growth.abort()
@@ -2000,7 +2012,7 @@ def test_table_grows_like_the_reference_defaultdict(pkg, n):
     assert np.array_equal(kg[np.lexsort(kg.T[::-1])], kf[np.lexsort(kf.T[::-1])])   # the same key set
     assert ag.verify_table()["rows"] == len(kf) == ag.stats()["inserts"] and ag.stats()["drops"] == 0
     # the C entry points' argument errors
-    L = pkg._native.lib()
+    L = LIB(pkg)
     out, moved = C.c_void_p(), C.c_int64()
     own = ag.table._q2048_owner
     assert L.q2048_table_grow(own.ptr, ag.capacity_log2 - 1, ag.capacity_log2 + 1, 1, C.byref(out), C.byref(moved), None) == -2

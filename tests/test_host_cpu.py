@@ -24,6 +24,9 @@ def test_abi_exports_every_declared_symbol(pkg):
     lib = C.CDLL(pkg._native.LIB_PATH)          # loads without a GPU: no compute calls here
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/q2048.h but not exported"
+    host = C.CDLL(pkg._native.HOST_LIB_PATH)    # the CPU twin exports the same ABI, symbol for symbol
+    for name in sorted(declared):
+        assert hasattr(host, name), f"{name} declared in include/q2048.h but not exported by libq2048_host.so"
     assert set(pkg._native._SIGNATURES) == declared
     L = pkg._native.lib()
     assert L.q2048_abi_version() == pkg._native.ABI_VERSION == 5

@@ -1,0 +1,122 @@
+"""The CPU twin (libq2048_host.so, device "cpu") under the parity tests of the HIP path.
+
+`tests/test_gpu_parity.py` is loaded a second time with its device set to "cpu", and the tests listed below --
+the golden fixtures generated from the reference (G2, G4, G5, G8), the exhaustive line table, the oracle
+comparisons of the env, the agent, the fused rollout, the deterministic step, the adapters with the reference's
+Python types, checkpoints -- run through the SAME Python host code and the SAME C ABI against the host library,
+in the CPU suite, with no GPU.  The host library is an explicit device: these tests also check that it is never
+what a "cuda" request gets."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+_spec = importlib.util.spec_from_file_location("q2048_parity_on_cpu", os.path.join(REPO, "tests", "test_gpu_parity.py"))
+_par = importlib.util.module_from_spec(_spec)
+sys.modules["q2048_parity_on_cpu"] = _par
+_spec.loader.exec_module(_par)
+_par.DEV = "cpu"
+
+ON_CPU = [
+    "test_env_init_matches_oracle", "test_golden_g2_moves_on_device", "test_golden_g4_env_step_on_device",
+    "test_exhaustive_lines_on_device", "test_stall_sequence_on_device", "test_bad_action_is_rejected_not_masked",
+    "test_abi_argument_errors", "test_golden_g8_dqn_env_on_device", "test_env_profiles_fused_and_unfused_match_oracle",
+    "test_play_only_never_touches_the_table", "test_env_rollout_matches_oracle", "test_golden_g5_choose_on_device",
+    "test_golden_g5_td_on_device", "test_single_env_loop_matches_oracle",
+    "test_fused_rollout_matches_oracle_independent_lanes", "test_strict_td_mode_equals_default_on_private_rows",
+    "test_fused_equals_unfused_and_split_launches", "test_env_step_to_two_buffers",
+    "test_shared_table_pure_exploration_trajectories_exact", "test_sharding_invariance",
+    "test_reference_surface_adapters", "test_5x5_env_init_and_rollout_match_oracle",
+    "test_5x5_fused_rollout_matches_oracle_independent_lanes", "test_5x5_fused_equals_unfused",
+    "test_5x5_shared_table_pure_exploration", "test_table_full_drops_are_counted_not_raised",
+    "test_checkpoint_resume_is_bit_exact", "test_export_dict_is_the_reference_table",
+    "test_row_tuple_single_env_matches_oracle", "test_episode_log_matches_reference_csv_rows",
+    "test_legal_moves_mask", "test_encode_onehot_matches_reference_encoder", "test_tile_overflow_is_reported",
+    "test_steps_counter_and_argument_checks", "test_deterministic_mode_batch_edges",
+    "test_no_learn_rollout_reads_but_never_writes",
+]
+for _name in ON_CPU:
+    globals()[_name.replace("_on_device", "") + "_on_cpu"] = getattr(_par, _name)
+
+
+def test_the_host_library_is_an_explicit_device_only(pkg):
+    N = pkg._native
+    assert os.path.samefile(N.HOST_LIB_PATH, os.path.join(os.path.dirname(pkg.__file__), "csrc", "libq2048_host.so"))
+    host = N.lib_for(torch.device("cpu"))
+    assert host is N.host_lib() and host.q2048_abi_version() == N.ABI_VERSION
+    assert host is not N.lib() and N.lib_for(torch.device("cuda")) is N.lib()      # never one for the other
+    with pytest.raises(ValueError):
+        N.lib_for(torch.device("meta"))
+    if not torch.cuda.is_available():                    # a "cuda" request without a GPU raises; it is not served by the host library
+        with pytest.raises(RuntimeError):
+            pkg.BatchedGame2048Env(4, device="cuda")
+    # the device allocator has no host form, and says so
+    import ctypes as C
+    out = C.c_void_p()
+    assert host.q2048_table_alloc(20, 0, C.byref(out)) == -4 and host.q2048_table_reserve(20, 22, 0, C.byref(out)) == -4
+
+
+def test_host_tables_are_device_tables_byte_for_byte(pkg, O):
+    """Same slot layout, same hash, same probe sequence: a table trained by the host library reads back through
+    q2048_table_export row for row as the oracle's dict (G6's job: one env, epsilon-greedy, 300 steps), and the
+    slot every key sits in is the one the device's probe sequence (home line first, then the next lines) gives."""
+    env = pkg.BatchedGame2048Env(1, seed=7, device="cpu")
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.99, exploration_rate=0.3,
+                                      capacity_log2=12, seed=7, device="cpu")
+    agent.fused_rollout(env, 300)
+    envs = O.envs_init(1, 4, 7, 0)
+    oa = O.Agent(100, 4, 0.1, 0.99, 0.3)
+    O.rollout(envs, oa, 300, 7, 0, 0)
+    boards, vals = oa.dump()                             # uint8 [R, 16] log2 boards
+    keys = (boards.astype(np.uint64) << (4 * np.arange(16, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+    k, q = agent.export_rows()
+    o1, o2 = np.argsort(keys), np.argsort(k)
+    assert np.array_equal(keys[o1], k[o2]) and np.allclose(q[o2], vals[o1], rtol=1e-5, atol=1e-6)
+    raw = agent.table.numpy().view(np.uint64).reshape(-1, 4)
+    occupied = np.nonzero(raw[:, 0])[0]
+    assert len(occupied) == len(keys)
+    lines = 1 << 10
+    for slot in occupied[:64]:                           # every row lies on its key's bucketised sequence
+        h = int(pkg_mix64(int(raw[slot, 0])))
+        line0, off = (h & 0xFFF) >> 2, h & 3
+        pos = (((int(slot) >> 2) - line0) % lines) * 4 + ((int(slot) - off) & 3)
+        assert pos < 64, (slot, pos)
+
+
+def pkg_mix64(x):
+    """q2048::mix64 (csrc/q2048_core.hpp), restated for the layout check."""
+    m = (1 << 64) - 1
+    x = (x * 0x9E3779B97F4A7C15) & m
+    x ^= x >> 29
+    x = (x * 0xBF58476D1CE4E5B9) & m
+    x ^= x >> 32
+    return x
+
+
+def test_train_py_on_the_cpu_device_reproduces_g6(pkg, tmp_path):
+    """`train.py --num-envs 1 --device cpu --episodes 30`: the reference's loop body on the drop-in adapters, on
+    the CPU twin -- the rows of its log are the reference's rows of G6 (same seed, draws injected into the
+    reference when the fixture was made)."""
+    import csv
+    import subprocess
+
+    g = dict(np.load(os.path.join(REPO, "tests", "golden", "g6_episodes_seed0.npz"), allow_pickle=False))
+    assert int(g["env_id0"]) == 0 and int(g["B"]) == 1 and bool(g["decay"])
+    E = int(g["E"])
+    p = subprocess.run([sys.executable, os.path.join(REPO, "train.py"), "--num-envs", "1", "--device", "cpu",
+                        "--episodes", str(E), "--seed", str(int(g["seed"])), "--alpha", repr(float(g["lr"])),
+                        "--gamma", repr(float(g["gamma"])), "--epsilon", repr(float(g["eps0"])), "--log", "cpu.csv"],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = list(csv.reader(open(tmp_path / "cpu.csv")))[1:]
+    ends = np.flatnonzero(g["dones"])
+    assert len(rows) == E == len(ends)
+    for e, (row, idx) in enumerate(zip(rows, ends)):     # Episode, Action, Q-Values, Reward, Total-Reward, Max Value
+        assert int(row[0]) == e and int(row[1]) == g["actions"][idx] and int(row[5]) == g["maxes"][idx]
+        assert np.float32(float(row[3])) == np.float32(g["rewards"][idx])
+        assert np.isclose(float(row[4]), g["ep_returns"][e], rtol=1e-5)

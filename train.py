@@ -45,7 +45,10 @@ def parse_args(argv=None):
                         "starts its own N ranks (one per GPU); under torchrun it joins the given group")
     p.add_argument("--board-size", type=int, default=4)
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--device", default="cuda")
+    p.add_argument("--device", default="cuda",
+                   help='"cuda[:i]" (MI355X, the HIP library) or "cpu": the CPU twin (libq2048_host.so: the same C ABI '
+                        "compiled for the host from the kernels' own per-lane arithmetic) -- an explicit device, never "
+                        "a fallback")
     p.add_argument("--steps-per-launch", type=int, default=64)
     p.add_argument("--capacity-log2", type=int, default=0,
                    help="Q-table slots = 2^n, fixed; 0 (default) = a table that grows like the reference's "
@@ -107,8 +110,10 @@ def log_debug_info(file_path, episode, action, q_values, reward, total_reward, m
 
 def train_single(args, pkg):
     """Agent/main.py:65-115 with the adapters: the loop body below is the reference's."""
+    # (play_first_board: the reset before the first episode keeps the constructor's game, so that this loop plays
+    # what lane 0 of the batched rollout plays and what the golden transcript G6 recorded -- draw for draw)
     env = pkg.Game2048_env(device=args.device, seed=args.seed, profile=args.env_profile,  # :66
-                           reset_shaping_state=args.reset_shaping_state)
+                           reset_shaping_state=args.reset_shaping_state, play_first_board=not args.resume)
     num_episodes = args.episodes                                                       # :67
     agent = pkg.QLearningAgent(num_episodes, action_space=env.action_space.n,          # :68
                                learning_rate=args.alpha, discount_factor=args.gamma,
