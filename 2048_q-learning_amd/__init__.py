@@ -7,7 +7,9 @@ running as hand-written HIP kernels for gfx950 behind the C ABI of include/q2048
 The directory name is not a Python identifier; import it with
     importlib.import_module("2048_q-learning_amd")
 or through the repo-root shim `q2048_amd.py`.  The package needs the in-tree
-csrc/libq2048_hip.so (built by __graft_entry__.build()); there is no CPU fallback.
+csrc/libq2048_hip.so (built by __graft_entry__.build()).  Nothing is ever substituted for it: the
+device "cpu" -- csrc/libq2048_host.so, the same C ABI compiled for the host from the kernels' own
+per-lane arithmetic -- exists only for callers that ask for it by name.
 """
 from . import _native
 from ._native import NativeError, build

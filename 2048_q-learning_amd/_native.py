@@ -182,6 +182,7 @@ _SIGNATURES = {
                                    C.POINTER(C.c_int64), C.c_void_p]),
     "q2048_table_grow_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "q2048_table_grow_poll": (C.c_int, [C.c_void_p]),
+    "q2048_table_grow_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "q2048_table_grow_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p]),
     "q2048_table_grow_finish": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "q2048_table_grow_abort": (C.c_int, [C.c_void_p]),

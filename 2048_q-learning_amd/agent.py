@@ -175,6 +175,13 @@ class _Growth:
         """True when the next call (commit, or finish after the commit) will not block."""
         return N.lib().q2048_table_grow_poll(self.handle) != N.PENDING   # (a failure is "ready": the next call reports it)
 
+    def wait(self) -> float:
+        """q2048_table_grow_wait: blocks until the bigger table is mapped; returns the ms the host thread spent on
+        it (a failure is left for `commit` to report)."""
+        ms = C.c_double(0.0)
+        N.lib().q2048_table_grow_wait(self.handle, C.byref(ms))
+        return float(ms.value)
+
     def commit(self, key_words: int, stream, verify_count: bool = False) -> _ChunkedTable:
         """q2048_table_grow_commit: the move is queued on `stream`; the bigger table is the table from here on."""
         ptr = C.c_void_p()
@@ -689,6 +696,7 @@ class BatchedQLearningAgent:
         ev[1].record()
         self.table = bigger.tensor(self.device)           # every launch from here on takes the new table
         self.table._q2048_owner = bigger
+        g.info.setdefault("prepare_ms", round(g.wait(), 3))  # (ready by now: the commit has returned)
         g.info.update({"from_log2": self.capacity_log2, "to_log2": g.new_capacity_log2, "expected_rows": int(rows),
                        "at_step": self.ctr, "host_ms": round((time.perf_counter() - t0) * 1e3, 3), "events": ev})
         self.capacity_log2 = g.new_capacity_log2
@@ -710,6 +718,17 @@ class BatchedQLearningAgent:
             raise RuntimeError(f"Q-table self-check failed at the growth 2^{g.info['from_log2']} -> "
                                f"2^{g.info['to_log2']}: {moved} occupied slots moved, {g.info['expected_rows']} rows "
                                "created according to the kernels' counters")
+
+    def wait_for_prefetch(self) -> "float | None":
+        """Blocks until the table a prefetched growth is mapping is ready and returns what the library's host thread
+        spent on it in ms (None: nothing is being prepared).  For a caller that wants the wait in its set-up rather
+        than in its run: hipMemCreate of tens of GiB takes milliseconds on memory that has been free for a while and
+        seconds when the driver is still wiping what a process released moments before."""
+        if self._growth is None:
+            return None
+        ms = self._growth.wait()
+        self._growth.info["prepare_ms"] = round(ms, 3)
+        return ms
 
     def release_retired(self) -> None:
         """Gives the tables that earlier growths left behind back to the device now (q2048_table_trim): the library

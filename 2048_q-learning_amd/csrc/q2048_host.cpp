@@ -34,7 +34,8 @@ namespace {
 using namespace q2048;
 using u64 = unsigned long long;
 
-constexpr uint32_t kMaxProbe = 1u << 14;   // as the device: the limit that makes a probe of a FULL table end
+// as the device: the limits that make a probe of a FULL table end (bulk moves and lookups / the learning paths)
+constexpr uint32_t kMaxProbe = 1u << 14, kRolloutProbe = 1u << 10;
 constexpr int kMaxCas = 16;
 constexpr int kMaxAwait = 1 << 20;
 
@@ -85,7 +86,7 @@ inline u64 seq_slot(const Seq& s, uint32_t p) {
 inline uint32_t seq_pos(const Seq& s, u64 slot) {
   return ((uint32_t)(((slot >> 2) - s.line0) & s.lmask) << 2) | (((uint32_t)slot - s.off) & 3u);
 }
-inline uint32_t probe_limit(u64 mask) { return mask >= (u64)kMaxProbe ? kMaxProbe : (uint32_t)mask + 1u; }
+inline uint32_t probe_limit(u64 mask, uint32_t maxp) { return mask >= (u64)maxp ? maxp : (uint32_t)mask + 1u; }
 
 struct Row { float q0, q1, q2, q3; };
 inline float row_get(const Row& r, int a) { return a == 0 ? r.q0 : a == 1 ? r.q1 : a == 2 ? r.q2 : r.q3; }
@@ -121,10 +122,10 @@ inline void publish(q2048_slot* s, const Geo<5>::Key& key) { __atomic_store_n(&s
 constexpr int64_t kNoSlot = INT64_MIN;
 // slot index (>= 0) when present, else ~h (h = the empty slot that ended the probe) or kNoSlot (probe limit)
 template <class Key>
-inline int64_t probe_find(const q2048_slot* table, u64 mask, const Key& key, Row& row) {
+inline int64_t probe_find(const q2048_slot* table, u64 mask, const Key& key, Row& row, uint32_t maxp = kRolloutProbe) {
   const Seq sq = seq_of(key_hash(key), mask);
   row = Row{0.f, 0.f, 0.f, 0.f};
-  for (uint32_t p = 0, lim = probe_limit(mask); p < lim; ++p) {
+  for (uint32_t p = 0, lim = probe_limit(mask, maxp); p < lim; ++p) {
     const u64 i = seq_slot(sq, p);
     const u64 k = ld_u64(&table[i].key);
     if (k == 0ull) return ~(int64_t)i;
@@ -134,11 +135,12 @@ inline int64_t probe_find(const q2048_slot* table, u64 mask, const Key& key, Row
 }
 // find-or-create from slot `start` of the key's sequence on
 template <class Key>
-inline int64_t probe_insert(q2048_slot* table, u64 mask, const Key& key, u64 start, bool& inserted) {
+inline int64_t probe_insert(q2048_slot* table, u64 mask, const Key& key, u64 start, bool& inserted,
+                            uint32_t maxp = kRolloutProbe) {
   const Seq sq = seq_of(key_hash(key), mask);
   inserted = false;
   u64 i = start & mask;
-  for (uint32_t p = seq_pos(sq, i), lim = probe_limit(mask); p < lim; i = seq_slot(sq, ++p)) {
+  for (uint32_t p = seq_pos(sq, i), lim = probe_limit(mask, maxp); p < lim; i = seq_slot(sq, ++p)) {
     uint64_t k = ld_u64(&table[i].key);
     if (k == 0ull) {
       uint64_t expect = 0ull;
@@ -428,7 +430,7 @@ void q_lookup_impl_n(const q2048_slot* table, u64 mask, const uint8_t* boards, i
       const uint64_t id = (flags & Q2048_FLAG_SINGLE_ENV) ? env_id0 : env_id0 + (uint64_t)i;
       const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
       Row r;
-      const int64_t slot = probe_find(table, mask, state_key(b, salt, status), r);
+      const int64_t slot = probe_find(table, mask, state_key(b, salt, status), r, kMaxProbe);
       q_out[4 * i] = r.q0; q_out[4 * i + 1] = r.q1; q_out[4 * i + 2] = r.q2; q_out[4 * i + 3] = r.q3;
       if (found != nullptr) found[i] = slot >= 0;
     }
@@ -843,6 +845,7 @@ int q2048_table_alloc(int, size_t, q2048_slot** out) { if (out) *out = nullptr; 
 int q2048_table_reserve(int, int, size_t, q2048_slot** out) { if (out) *out = nullptr; return Q2048_ERR_UNSUPPORTED; }
 int q2048_table_grow_begin(q2048_slot*, int, int, q2048_growth** out) { if (out) *out = nullptr; return Q2048_ERR_UNSUPPORTED; }
 int q2048_table_grow_poll(q2048_growth*) { return Q2048_ERR_UNSUPPORTED; }
+int q2048_table_grow_wait(q2048_growth*, double*) { return Q2048_ERR_UNSUPPORTED; }
 int q2048_table_grow_commit(q2048_growth*, int, uint32_t, q2048_slot** out, void*) { if (out) *out = nullptr; return Q2048_ERR_UNSUPPORTED; }
 int q2048_table_grow_finish(q2048_growth*, int64_t*) { return Q2048_ERR_UNSUPPORTED; }
 int q2048_table_grow_abort(q2048_growth*) { return Q2048_ERR_UNSUPPORTED; }
@@ -893,10 +896,10 @@ int q2048_table_import(q2048_slot* table, int cap_log2, const uint64_t* keys, co
       int64_t slot;
       if (key_words == 1) {
         const Geo<4>::Key key{(u64)keys[i]};
-        slot = probe_insert(table, mask, key, key_hash(key) & mask, inserted);
+        slot = probe_insert(table, mask, key, key_hash(key) & mask, inserted, kMaxProbe);
       } else {
         const Geo<5>::Key key{(u64)keys[2 * i], (u64)keys[2 * i + 1]};
-        slot = probe_insert(table, mask, key, key_hash(key) & mask, inserted);
+        slot = probe_insert(table, mask, key, key_hash(key) & mask, inserted, kMaxProbe);
       }
       if (slot < 0) { status_or(status, Q2048_STATUS_TABLE_FULL); continue; }
       for (int a = 0; a < 4; ++a) st_f32(&table[slot].q[a], q[4 * i + a]);

@@ -44,11 +44,16 @@ namespace {
 using namespace q2048;
 
 constexpr int kBlock = 256;
-// Probe limit: beyond it a lookup reads "absent" and an update drops (counted; status TABLE_FULL).  It is
+// Probe limits: beyond them a lookup reads "absent" and an update drops (counted; status TABLE_FULL).  They are
 // what makes a probe of a FULL table end, not a load policy: at load 0.93 the longest cluster of a 2^22-slot
 // table is already thousands of slots (ln n / (a - 1 - ln a)), and round 3's limit of 256 made "full" mean
-// "load ~0.85" (a racing import at load 0.93 dropped rows).  2^14 slots, or the whole table if smaller.
-constexpr uint32_t kMaxProbe = 1u << 14;
+// "load ~0.85" (a racing import at load 0.93 dropped rows).  Bulk moves of rows (import, the rehash of a growth)
+// and q2048_q_lookup take kMaxProbe = 2^14 slots: they must place and find every row of a table the caller sized.
+// The learning paths (rollouts, choose, update) take kRolloutProbe = 2^10: a lane of a rollout probes twice per
+// step, and on a fixed table that has filled up 2^14 dependent 16-byte loads per probe made a launch orders of
+// magnitude slower before TABLE_FULL became visible; 2^10 bounds that at ~load 0.93, where an
+// absent key's expected probe is 100 slots already.  (Or the whole table if smaller.)
+constexpr uint32_t kMaxProbe = 1u << 14, kRolloutProbe = 1u << 10;
 constexpr int kMaxCas = 16;      // TD compare-and-swap attempts before the update is simply stored
 
 static_assert(sizeof(q2048_aux) == 16 && sizeof(q2048_slot) == 32, "ABI layout");
@@ -213,8 +218,8 @@ __device__ __forceinline__ uint32_t seq_pos(const Seq& s, u64 slot) { // inverse
   return ((uint32_t)(((slot >> 2) - s.line0) & s.lmask) << 2) | (((uint32_t)slot - s.off) & 3u);
 }
 
-__device__ __forceinline__ uint32_t probe_limit(u64 mask) {
-  return mask >= (u64)kMaxProbe ? kMaxProbe : (uint32_t)mask + 1u;
+__device__ __forceinline__ uint32_t probe_limit(u64 mask, uint32_t maxp) {
+  return mask >= (u64)maxp ? maxp : (uint32_t)mask + 1u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -298,11 +303,12 @@ __device__ __forceinline__ u32x4 ld16_agent(const void* p) {  // waited for in p
   return v;
 }
 __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
-                                              const Geo<4>::Key& key, Row& row, bool& created) {
+                                              const Geo<4>::Key& key, Row& row, bool& created,
+                                              uint32_t maxp = kRolloutProbe) {
   const Seq sq = seq_of(key_hash(key), mask);
   created = false;
   row = Row{0.f, 0.f, 0.f, 0.f};
-  for (uint32_t p = 0, lim = probe_limit(mask); p < lim; ++p) {
+  for (uint32_t p = 0, lim = probe_limit(mask, maxp); p < lim; ++p) {
     const u64 i = seq_slot(sq, p);
     const u32x4 v = ld16_agent(&table[i]);
     const u64 k = (u64)v.x | ((u64)v.y << 32);
@@ -320,11 +326,12 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
 // a hit instead of four (key, second word, two row halves).  A slot whose second word is still 0
 // is being created by its owner: wait for the word (`confirm`).
 __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
-                                              const Geo<5>::Key& key, Row& row, bool& created) {
+                                              const Geo<5>::Key& key, Row& row, bool& created,
+                                              uint32_t maxp = kRolloutProbe) {
   const Seq sq = seq_of(key_hash(key), mask);
   created = false;
   row = Row{0.f, 0.f, 0.f, 0.f};
-  for (uint32_t p = 0, lim = probe_limit(mask); p < lim; ++p) {
+  for (uint32_t p = 0, lim = probe_limit(mask, maxp); p < lim; ++p) {
     const u64 i = seq_slot(sq, p);
     const u32x4 a = ld16_agent(&table[i]);
     const u64 k = (u64)a.x | ((u64)a.y << 32);
@@ -347,12 +354,12 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
 // a moment ago.  Returns the slot index or kNoSlot (probe limit: the caller drops the update).
 template <class Key>
 __device__ __forceinline__ int64_t probe_insert(q2048_slot* table, u64 mask, const Key& key, u64 start,
-                                                bool& inserted) {
+                                                bool& inserted, uint32_t maxp = kRolloutProbe) {
   const Seq sq = seq_of(key_hash(key), mask);
   u64 i = start & mask;
   inserted = false;
   u64 k = 0ull;                                      // the hinted slot: straight to the compare-and-swap
-  for (uint32_t p = seq_pos(sq, i), lim = probe_limit(mask); p < lim; i = seq_slot(sq, ++p), k = ld_u64(&table[i].key)) {
+  for (uint32_t p = seq_pos(sq, i), lim = probe_limit(mask, maxp); p < lim; i = seq_slot(sq, ++p), k = ld_u64(&table[i].key)) {
     if (k == 0ull) k = atomicCAS(reinterpret_cast<u64*>(&table[i].key), 0ull, key.k0);
     if ((k == 0ull || k == key.k0) && confirm(&table[i], key, k == 0ull, inserted)) return (int64_t)i;
   }
@@ -789,38 +796,52 @@ template <> struct RowCache<4> { u64 key; float q[4]; u64 slot; };              
 template <> struct RowCache<5> { u64 key; float q[4]; u64 key_hi; u64 slot; u64 pad; }; // 48 B
 static_assert(sizeof(RowCache<4>) == 32 && sizeof(RowCache<5>) == 48, "ABI layout");
 
-__device__ __forceinline__ bool cache_get(const RowCache<4>* c, int64_t i, const Geo<4>::Key& key, Row& r,
+// A record also carries, in the 24 bits above its 40-bit slot index, a TAG of the table it was read from (a hash
+// of the table's address and capacity): a record left by a launch on another table -- the table has grown, or the
+// caller switched tables and did not zero the cache -- never matches, so its slot index is never used against the
+// wrong table (records outlive launches since round 4 and were trusted on a key match alone).  A table
+// rewritten IN PLACE (zero-filled, imported into) keeps its tag: the caller zero-fills the cache then, as before.
+__device__ __forceinline__ u64 cache_tag(const q2048_slot* table, u64 mask) {
+  return (mix64((u64)reinterpret_cast<uintptr_t>(table) ^ (mask * 0x9E3779B97F4A7C15ull)) >> 40) << 40;
+}
+constexpr u64 kCacheSlotMask = (1ull << 40) - 1ull;
+__device__ __forceinline__ bool cache_get(const RowCache<4>* c, int64_t i, const Geo<4>::Key& key, u64 tag, Row& r,
                                           int64_t& slot) {
   const uint4* p = reinterpret_cast<const uint4*>(c + i);
   const uint4 a = p[0], b = p[1];
-  if (((u64)a.x | ((u64)a.y << 32)) != key.k0) return false;
+  const u64 s = (u64)b.z | ((u64)b.w << 32);
+  if (((u64)a.x | ((u64)a.y << 32)) != key.k0 || (s & ~kCacheSlotMask) != tag) return false;
   r = Row{bits_f32(a.z), bits_f32(a.w), bits_f32(b.x), bits_f32(b.y)};
-  slot = (int64_t)((u64)b.z | ((u64)b.w << 32));
+  slot = (int64_t)(s & kCacheSlotMask);
   return true;
 }
-__device__ __forceinline__ bool cache_get(const RowCache<5>* c, int64_t i, const Geo<5>::Key& key, Row& r,
+__device__ __forceinline__ bool cache_get(const RowCache<5>* c, int64_t i, const Geo<5>::Key& key, u64 tag, Row& r,
                                           int64_t& slot) {
   const uint4* p = reinterpret_cast<const uint4*>(c + i);
   const uint4 a = p[0], b = p[1], d = p[2];
-  if (((u64)a.x | ((u64)a.y << 32)) != key.k0 || ((u64)b.z | ((u64)b.w << 32)) != key.k1) return false;
+  const u64 s = (u64)d.x | ((u64)d.y << 32);
+  if (((u64)a.x | ((u64)a.y << 32)) != key.k0 || ((u64)b.z | ((u64)b.w << 32)) != key.k1 || (s & ~kCacheSlotMask) != tag)
+    return false;
   r = Row{bits_f32(a.z), bits_f32(a.w), bits_f32(b.x), bits_f32(b.y)};
-  slot = (int64_t)((u64)d.x | ((u64)d.y << 32));
+  slot = (int64_t)(s & kCacheSlotMask);
   return true;
 }
-__device__ __forceinline__ void cache_put(RowCache<4>* c, int64_t i, const Geo<4>::Key& key, const Row& r,
+__device__ __forceinline__ void cache_put(RowCache<4>* c, int64_t i, const Geo<4>::Key& key, u64 tag, const Row& r,
                                           int64_t slot) {
   const u64 k = slot >= 0 ? key.k0 : 0ull;             // no row (table full): nothing to remember
+  const u64 s = ((u64)slot & kCacheSlotMask) | tag;
   uint4* p = reinterpret_cast<uint4*>(c + i);
   p[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), f32_bits(r.q0), f32_bits(r.q1));
-  p[1] = make_uint4(f32_bits(r.q2), f32_bits(r.q3), (uint32_t)(u64)slot, (uint32_t)((u64)slot >> 32));
+  p[1] = make_uint4(f32_bits(r.q2), f32_bits(r.q3), (uint32_t)s, (uint32_t)(s >> 32));
 }
-__device__ __forceinline__ void cache_put(RowCache<5>* c, int64_t i, const Geo<5>::Key& key, const Row& r,
+__device__ __forceinline__ void cache_put(RowCache<5>* c, int64_t i, const Geo<5>::Key& key, u64 tag, const Row& r,
                                           int64_t slot) {
   const u64 k = slot >= 0 ? key.k0 : 0ull;
+  const u64 s = ((u64)slot & kCacheSlotMask) | tag;
   uint4* p = reinterpret_cast<uint4*>(c + i);
   p[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), f32_bits(r.q0), f32_bits(r.q1));
   p[1] = make_uint4(f32_bits(r.q2), f32_bits(r.q3), (uint32_t)key.k1, (uint32_t)(key.k1 >> 32));
-  p[2] = make_uint4((uint32_t)(u64)slot, (uint32_t)((u64)slot >> 32), 0u, 0u);
+  p[2] = make_uint4((uint32_t)s, (uint32_t)(s >> 32), 0u, 0u);
 }
 
 template <int N>
@@ -847,7 +868,7 @@ __global__ __launch_bounds__(kBlock) void k_q_choose(const q2048_slot* table, u6
     bool made;
     int64_t slot;
     const auto key = state_key(b, salt, status);
-    if (cache == nullptr || !cache_get(cache, i, key, r, slot)) probe_find(table, mask, key, r, made);
+    if (cache == nullptr || !cache_get(cache, i, key, cache_tag(table, mask), r, slot)) probe_find(table, mask, key, r, made);
     act = argmax4(r.q0, r.q1, r.q2, r.q3);
   }
   actions[i] = (uint8_t)act;
@@ -866,7 +887,7 @@ __global__ __launch_bounds__(kBlock) void k_q_lookup(const q2048_slot* table, u6
   const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
   Row r;
   bool made;
-  const int64_t slot = probe_find(table, mask, state_key(b, salt, status), r, made);
+  const int64_t slot = probe_find(table, mask, state_key(b, salt, status), r, made, kMaxProbe);
   reinterpret_cast<float4*>(q_out)[i] = make_float4(r.q0, r.q1, r.q2, r.q3);
   if (found != nullptr) found[i] = slot >= 0;
 }
@@ -910,7 +931,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
       // probe; the defaultdict creates the row when absent, so do we
       Row rs;
       int64_t slot = kNoSlot;
-      if (cache == nullptr || !cache_get(cache, i, key_s, rs, slot)) {
+      if (cache == nullptr || !cache_get(cache, i, key_s, cache_tag(table, mask), rs, slot)) {
         slot = probe_find(table, mask, key_s, rs, ins_s);
         if (slot < 0 && slot != kNoSlot) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
       }
@@ -936,7 +957,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
       bool ins_c = false;
       slot_n = claim_resolve(table, mask, key_n, claim, slot_n, ins_c);
       ins_n = ins_n || ins_c;
-      if (cache != nullptr) cache_put(cache, i, key_n, rn, slot_n);
+      if (cache != nullptr) cache_put(cache, i, key_n, cache_tag(table, mask), rn, slot_n);
     }
     const uint32_t n_ins = wave_count(ins_n) + wave_count(ins_s), n_drop = wave_count(dropped);
     if (tdc.retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)tdc.retries);
@@ -1037,7 +1058,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     // cache when the board is still the one it left -- a coalesced 32-byte read -- else a probe (one
     // scattered 128-byte request per lane: 21.5 us of every launch at 1 Mi boards)
     int64_t slot_s = kNoSlot;
-    if (!play_only && (cache == nullptr || !cache_get(cache, i, key_s, q, slot_s)))
+    if (!play_only && (cache == nullptr || !cache_get(cache, i, key_s, cache_tag(table, mask), q, slot_s)))
       slot_s = probe_find(table, mask, key_s, q, made0);
     Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
@@ -1133,7 +1154,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     st_aux(aux, i, a);
     // hand the carried row to this env's next launch / choose_action / update_q_value (a state whose
     // row does not exist yet -- an episode began on the last step -- leaves an empty record)
-    if (!play_only && cache != nullptr) cache_put(cache, i, key_s, q, slot_s);
+    if (!play_only && cache != nullptr) cache_put(cache, i, key_s, cache_tag(table, mask), q, slot_s);
 
     if (n_drop) atomicOr(status, Q2048_STATUS_TABLE_FULL);
     if (tdc.retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)tdc.retries);
@@ -1801,7 +1822,7 @@ __global__ __launch_bounds__(kBlock) void k_table_import(q2048_slot* table, u64 
   key.k0 = keys[i * WORDS];
   if constexpr (WORDS == 2) key.k1 = keys[i * 2 + 1];
   bool inserted;
-  const int64_t slot = probe_insert(table, mask, key, key_home(key, mask), inserted);
+  const int64_t slot = probe_insert(table, mask, key, key_home(key, mask), inserted, kMaxProbe);
   if (slot < 0) { atomicOr(status, Q2048_STATUS_TABLE_FULL); return; }
   const float4 v = reinterpret_cast<const float4*>(q)[i];
   table[slot].q[0] = v.x; table[slot].q[1] = v.y; table[slot].q[2] = v.z; table[slot].q[3] = v.w;
@@ -1828,7 +1849,7 @@ __global__ __launch_bounds__(kBlock) void k_table_rehash(const q2048_slot* old_t
     key.k0 = k;
     if constexpr (WORDS == 2) key.k1 = (u64)w.z | ((u64)w.w << 32);
     bool inserted;
-    const int64_t slot = probe_insert(new_t, new_mask, key, key_home(key, new_mask), inserted);
+    const int64_t slot = probe_insert(new_t, new_mask, key, key_home(key, new_mask), inserted, kMaxProbe);
     if (slot < 0 || !inserted) { ++failed; continue; }
     uint2* q = reinterpret_cast<uint2*>(new_t[slot].q);                  // 8-byte aligned (offset 8 of a 32-B slot)
     q[0] = make_uint2(a.z, a.w);
@@ -2735,6 +2756,7 @@ struct q2048_growth {
   int old_log2 = 0, new_log2 = 0;
   Family* fam = nullptr;
   int prepared = Q2048_PENDING;      // Q2048_PENDING while the worker maps the new table, then Q2048_OK or an error
+  double prepare_ms = 0.0;           // what the worker spent on it (reserve + create + map + zero-fill + verify)
   bool committed = false, verify_count = false;
   hipEvent_t moved = nullptr;        // recorded behind the rehash (and the counters' copy) on the caller's stream
 };
@@ -2829,9 +2851,13 @@ int q2048_table_grow_begin(q2048_slot* table, int cap_log2, int new_cap_log2, q2
   Worker::worker().post([g] {
     DeviceGuard guard(g->fam->dev);
     q2048_slot* bigger = nullptr;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     const int rc = map_table(g->fam, g->new_log2, &bigger);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     std::lock_guard<std::mutex> lock(g_growth_mutex);
     g->bigger = bigger;
+    g->prepare_ms = (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6;
     g->prepared = rc;
     g_growth_cv.notify_all();
   });
@@ -2846,6 +2872,17 @@ int q2048_table_grow_poll(q2048_growth* g) {
   if (!g->committed) return g->prepared;
   const hipError_t e = hipEventQuery(g->moved);
   return e == hipSuccess ? Q2048_OK : (e == hipErrorNotReady ? Q2048_PENDING : Q2048_ERR_LAUNCH);
+}
+
+int q2048_table_grow_wait(q2048_growth* g, double* prepare_ms) {
+  if (g == nullptr) return Q2048_ERR_NULL;
+  {
+    std::lock_guard<std::mutex> lock(g_growth_mutex);
+    if (!growth_is_live(g)) return Q2048_ERR_NULL;
+  }
+  const int rc = wait_prepared(g);
+  if (prepare_ms != nullptr) *prepare_ms = g->prepare_ms;
+  return rc;
 }
 
 int q2048_table_grow_commit(q2048_growth* g, int key_words, uint32_t flags, q2048_slot** table_out, void* stream) {

@@ -57,6 +57,79 @@ def rank_env(rank: int, world_size: int, master_addr: str, master_port: int, bas
     return env
 
 
+def _read(path: str):
+    try:
+        with open(path) as fh:
+            return fh.read()
+    except OSError:
+        return None
+
+
+def _cpulist(text: str) -> set:
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(sysfs: str = "/sys") -> list:
+    """NUMA node of every GPU, in the order of the KFD topology (= the HIP device order when no
+    *_VISIBLE_DEVICES variable re-orders it), read from sysfs alone: no GPU call.  -1 = unknown."""
+    root = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        ids = sorted(int(d) for d in os.listdir(root) if d.isdigit())
+    except OSError:
+        return []
+    out = []
+    for n in ids:
+        text = _read(os.path.join(root, str(n), "properties"))
+        if text is None:
+            continue
+        prop = dict(line.split()[:2] for line in text.splitlines() if len(line.split()) >= 2)
+        if int(prop.get("simd_count", "0")) == 0:            # a CPU node of the topology
+            continue
+        loc, dom = int(prop.get("location_id", "0")), int(prop.get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+        node = _read(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node"))
+        out.append(int(node) if node is not None and node.strip().lstrip("-").isdigit() else -1)
+    return out
+
+
+def pin_to_gpu_numa_node(local_rank: int, sysfs: str = "/sys", environ=None):
+    """Restricts THIS process to the CPUs of the NUMA node its GPU hangs on (`os.sched_setaffinity`): a rank's
+    launches, its statistics reads and the library's mapping thread then run next to their device instead of
+    across the socket link.  Called by a rank at its own start, before anything touches the GPU -- sysfs reads and
+    one affinity call, no re-exec, no child.  A *_VISIBLE_DEVICES list of plain indices is honoured; anything the
+    host does not expose (no KFD topology, node -1, an empty intersection with the current affinity) leaves the
+    process as it is.  Returns (node, cpus) when it pinned, else None."""
+    environ = os.environ if environ is None else environ
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    nodes = gpu_numa_nodes(sysfs)
+    index = int(local_rank)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        listed = environ.get(var)
+        if listed:
+            parts = [x.strip() for x in listed.split(",") if x.strip()]
+            if not all(x.isdigit() for x in parts) or not parts:
+                return None                                   # UUIDs: no mapping without a GPU call
+            index = int(parts[index % len(parts)])
+            break
+    if not nodes or not 0 <= index < len(nodes) or nodes[index] < 0:
+        return None
+    text = _read(os.path.join(sysfs, "devices", "system", "node", f"node{nodes[index]}", "cpulist"))
+    if text is None:
+        return None
+    cpus = _cpulist(text) & set(os.sched_getaffinity(0))
+    if not cpus:
+        return None
+    os.sched_setaffinity(0, cpus)
+    return nodes[index], sorted(cpus)
+
+
 # libc.prctl, resolved ONCE, here, in the parent: the child must not dlopen between fork and exec (if
 # another thread of the launcher held the loader's or malloc's lock at fork time, the child would
 # wait for it forever -- the launcher runs under pytest and inside callers that have threads)

@@ -36,9 +36,11 @@ Extra objects on the line:
                 (and `fabric_frac` = traffic / launch time / peak: how busy the memory system is, next to
                 `frac`, how well it is used, and `physical_minimum`, the run's own useful bytes) only when
                 the committed PMC passes were taken with this run's configuration on these kernel sources.
-  cpu_baseline  the CPU oracle (a C port of the reference loop, oracle/) timed on this host's
+  cpu_baseline  the CPU oracle (a C port of the reference loop, oracle/; kind "port") timed on this host's
                 cores on a bounded sample of the same workload (rank 0, after the GPU regions, at
-                every N): all cores and one thread, with the CPU model.
+                every N): all cores and one thread, with the CPU model; and, under `product_core`, the
+                product's own CPU twin (libq2048_host.so, device "cpu"; kind "product-core") on the same
+                cores: the kernels' per-lane arithmetic and table, one shared table as on the GPU.
   companions    the same protocol at SURVEY 8(d)'s 2^28-slot table, at eps = 0.01, on 5x5 boards and on a table
                 pre-filled (untimed) to load 0.45 -- the steady state of a long run; the main line's table is
                 young (N = 1 only).
@@ -243,6 +245,49 @@ def pkg_status_full() -> int:
     return 4   # Q2048_STATUS_TABLE_FULL
 
 
+def cpu_baseline_product_core(pkg, torch, args, seconds: float) -> dict:
+    """Kind 'product-core': the product's own CPU twin (libq2048_host.so: the C ABI compiled for the host from the
+    kernels' per-lane arithmetic, csrc/q2048_core.hpp -- SWAR boards, counter RNG, the same hash table) on this
+    host's cores, through the same Python classes with device="cpu": the same workload as the GPU line (one
+    SHARED table, Hogwild writes), bounded.  What the host cores can do with the product's code, next to the
+    reference's loop ported to C (kind 'port')."""
+    import numpy as np
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    runs, keep = {}, os.environ.get("Q2048_HOST_THREADS")
+    per = max(seconds / 5.0, 0.2)
+    try:
+        for T in sorted({1, min(16, cores), min(32, cores), max(1, cores // 4), cores}):
+            os.environ["Q2048_HOST_THREADS"] = str(T)
+            B, steps = 16384 * T, 24
+            env = pkg.BatchedGame2048Env(B, seed=args.seed, device="cpu")
+            cap = max(20, int(np.ceil(np.log2(2.0 * B * 64))))
+            agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
+                                              exploration_rate=args.eps, capacity_log2=cap, seed=args.seed, device="cpu")
+            agent.fused_rollout(env, 8)                               # warm-up
+            done, t0 = 0, time.perf_counter()
+            while True:
+                agent.fused_rollout(env, steps)
+                done += B * steps
+                dt = time.perf_counter() - t0
+                if dt > per or env.ctr > 56:
+                    break
+            runs[T] = (done / dt, B, env.ctr - 8, dt)
+            del agent, env
+    finally:
+        if keep is None:
+            os.environ.pop("Q2048_HOST_THREADS", None)
+        else:
+            os.environ["Q2048_HOST_THREADS"] = keep
+    T = max(runs, key=lambda t: runs[t][0])
+    rate, B, steps, dt = runs[T]
+    return {"value": rate, "unit": "env-steps/s", "cores": T, "kind": "product-core",
+            "sample": f"libq2048_host.so q2048_fused_rollout: {B} boards x {steps} steps, {T} thread(s) on ONE shared "
+                      f"table, {dt:.1f} s (host has {cores} usable cores)",
+            "single_thread": {"value": runs[1][0], "cores": 1},
+            "by_threads": {str(t): r[0] for t, r in sorted(runs.items())}}
+
+
 def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, steps, warmup, repeats,
             S, reducer, board_size=None, prefill_load=0.0):
     """The protocol of the module docstring for one configuration.  Returns a dict of raw
@@ -360,6 +405,12 @@ def summarise(m, shard, steps, algo_bytes):
 def run_rank(args):
     import torch
 
+    # a rank of a multi-GPU job sits on the CPUs next to its GPU (sysfs + sched_setaffinity, before any GPU call);
+    # the CPU leg at the end gets the process's original CPUs back
+    cpus_before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    pinned = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        pinned = load_launcher().pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")))
     pkg = importlib.import_module("2048_q-learning_amd")
     if args.experiment_bits:          # ablation bits exist in the measurement build only
         pkg._native.use_experiments_build()
@@ -522,8 +573,14 @@ def run_rank(args):
         pkg.dist.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
+        if pinned is not None:
+            out["config"]["rank0_cpu_affinity"] = {"numa_node": pinned[0], "cpus": len(pinned[1])}
+            os.sched_setaffinity(0, cpus_before)
         # the reference's CPU path next to the GPU number, on this node's cores, at every N
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds) if args.cpu_seconds > 0 else None
+        if out["cpu_baseline"] is not None:
+            # ... and what the same cores do with the product's own code (the CPU twin): both figures on the line
+            out["cpu_baseline"]["product_core"] = cpu_baseline_product_core(pkg, torch, args, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
 

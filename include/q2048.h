@@ -258,8 +258,11 @@ int q2048_q_update(q2048_slot *table, int cap_log2, const uint8_t *boards_s,
  * `next_state` unless an episode began, so an update costs one scattered row read instead of two
  * and a greedy choose none.  This is what the fused rollout carries in registers, handed over
  * through HBM as a stream; like it, a cached row does not see what OTHER envs wrote to it since.
- * Any calling pattern is correct (a record is used only on a key match); the caller zero-fills the
- * cache whenever the table is changed by other means (import, another rollout entry point). */
+ * Any calling pattern is correct: a record is used only when its key is the key of the board passed in AND it
+ * was left by a call on this very table (every record carries a 24-bit tag of the table's address and capacity:
+ * after a growth, or with another table, old records simply miss).  The caller zero-fills the cache when a table
+ * is rewritten IN PLACE by other means (zero-filled, imported into, updated through an entry point without the
+ * cache): the tag cannot see that. */
 size_t q2048_sizeof_rowcache(int n);
 int q2048_q_choose_cached(const q2048_slot *table, int cap_log2, const uint8_t *boards, int64_t B,
                           int n, double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr,
@@ -401,6 +404,9 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  *       (profiles/r05_vmm_cost_small_chunks.txt).
  *   q2048_table_grow_poll(g)      Q2048_OK: the next call (commit, or finish after a commit) will not block;
  *       Q2048_PENDING: it would; < 0: the preparation failed (commit returns the same code and ends the growth).
+ *   q2048_table_grow_wait(g, &ms)   blocks until the preparation is over (a caller that prefers to wait before its
+ *       clock starts rather than at the commit) and returns its outcome; ms (host double, may be NULL) = what the
+ *       host thread spent on it.
  *   q2048_table_grow_commit(g, key_words, flags, &bigger, stream)   waits for the preparation if need be, then
  *       enqueues the move (k_table_rehash, 18 G rows/s) on `stream`, behind whatever the caller queued on the old
  *       table, and returns the new table WITHOUT waiting for it: every launch queued on `stream` from here on
@@ -449,6 +455,7 @@ int q2048_table_alloc(int cap_log2, size_t chunk_bytes, q2048_slot **table_out);
 int q2048_table_reserve(int cap_log2, int max_cap_log2, size_t chunk_bytes, q2048_slot **table_out);
 int q2048_table_grow_begin(q2048_slot *table, int cap_log2, int new_cap_log2, q2048_growth **growth_out);
 int q2048_table_grow_poll(q2048_growth *growth);
+int q2048_table_grow_wait(q2048_growth *growth, double *prepare_ms);
 int q2048_table_grow_commit(q2048_growth *growth, int key_words, uint32_t flags, q2048_slot **table_out,
                             void *stream);
 int q2048_table_grow_finish(q2048_growth *growth, int64_t *rows_moved);

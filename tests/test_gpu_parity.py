@@ -723,6 +723,35 @@ def test_fused_rollout_row_cache_and_statistics_mirror(pkg, O, n):
 
 
 @pytest.mark.parametrize("n", [4, 5])
+def test_row_cache_records_are_bound_to_their_table(pkg, n):
+    """A row-cache record carries a tag of the table it was read from: a caller that moves to another
+    table -- a growth through the C API, a second table -- and hands the old cache over gets misses, not writes
+    through stale slot indices.  The table is swapped behind the agent's back (what a C caller that forgot to
+    zero the cache does): the next launch must probe, create its rows in the NEW table and leave no Q value in a
+    slot that has no key."""
+    B = 4096
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=21, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=0.5, capacity_log2=18, seed=21, device=DEV, board_size=n)
+    agent.fused_rollout(env, 8)
+    old = agent.table                                       # stays alive: the new table has another address
+    agent.table = torch.zeros_like(old)
+    assert agent.table.data_ptr() != old.data_ptr()
+    agent.stats(reset=True)
+    agent._inserts_folded = 0
+    agent._rebase_rows(0)
+    agent.fused_rollout(env, 8)                             # the cache still holds the old table's records
+    words = agent.table.view(torch.int64).reshape(-1, 4)
+    orphan = (words[:, 0] == 0) & ((words[:, 1] != 0) | (words[:, 2] != 0))
+    assert int(orphan.sum()) == 0                           # no Q value without a key
+    st = agent.stats()
+    assert agent.table_size() == st["inserts"] > B and st["drops"] == 0
+    _, found = agent.q_values(env.boards, return_found=True)
+    carried = agent._row_cache.view(torch.int64).reshape(B, -1)[:, 0] != 0      # envs whose row exists already
+    assert bool(found[carried].all())
+    del old
+
+
+@pytest.mark.parametrize("n", [4, 5])
 def test_four_call_loop_without_copies_and_row_cache(pkg, O, n):
     """The batched loop of Agent/main.py:92-100 written WITHOUT a board copy (step ping-pongs two
     buffers: the tensor that was env.boards stays the pre-step state) and with the row cache
@@ -1316,6 +1345,43 @@ def test_table_full_drops_are_counted_not_raised(pkg, O):
     envs = O.envs_init(B, 4, seed, 0)
     O.rollout(envs, O.Agent(100, 4, 0.1, 0.9, 1.0), steps, seed, 0, 0)
     assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16])
+
+
+@pytest.mark.parametrize("n", [4, 5])
+def test_rollout_on_a_full_table_stays_bounded(pkg, n):
+    """A FIXED table of 2^20 slots driven until it is full (with one probe limit of 2^14 for every
+    probe, each lookup of an absent key issued up to 16 384 dependent loads per lane, twice per step, and a launch
+    on a full table slowed by orders of magnitude before TABLE_FULL became visible).  The learning paths probe at
+    most 2^10 slots: launches on the full table stay within a small multiple of a launch on the young one, the
+    drops are counted, the status word says TABLE_FULL, and every row that was created is still found."""
+    import time
+
+    B, S, cap = 1 << 16, 8, 20
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=12, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2=cap, seed=12, device=DEV, board_size=n)
+
+    def launch():
+        sync()
+        t0 = time.perf_counter()
+        agent.fused_rollout(env, S)
+        sync()
+        return time.perf_counter() - t0
+
+    launch()
+    young = min(launch() for _ in range(3))
+    for _ in range(40):                                   # ~0.6 rows per env-step: the table fills in a few launches
+        agent.fused_rollout(env, S)
+    st = agent.stats()
+    rows = agent.table_size()
+    assert rows > 0.9 * (1 << cap) and st["drops"] > 0 and rows == st["inserts"]
+    assert agent.check_status() & pkg._native.STATUS_TABLE_FULL
+    full = max(launch() for _ in range(3))
+    print(f"[full table {n}x{n}] load {rows / (1 << cap):.3f}: {full * 1e3:.2f} ms per {S}-step launch against "
+          f"{young * 1e3:.2f} ms on the young table")
+    assert full < max(200 * young, 0.5), (full, young)
+    k, q = agent.export_rows()                            # every created row is in the table, once
+    assert len(q) == rows and len(np.unique(k.reshape(len(q), -1), axis=0)) == rows
+    assert pkg._native.claim_timeouts(LIB(pkg)) == 0
 
 
 @pytest.mark.parametrize("n", [4, 5])

@@ -3,6 +3,7 @@ declares, host logic (epsilon schedule, sharding, statistics all-reduce over glo
 world_size 2), loud failure without a device, and no product import of the oracle."""
 import ctypes as C
 import importlib
+import importlib.util
 import json
 import os
 import re
@@ -133,9 +134,14 @@ def test_product_fails_loudly_without_gpu(pkg):
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no HIP device|MI355X"):
-        pkg.BatchedGame2048Env(8)
+        pkg.BatchedGame2048Env(8)                        # the default device is "cuda": no silent move to the CPU twin
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pkg.BatchedQLearningAgent(10, device="cuda:0")
     with pytest.raises(RuntimeError):
-        pkg.BatchedQLearningAgent(10, device="cpu")
+        pkg.BatchedQLearningAgent(10, device="meta")
+    # the product also never reaches for the host library on its own: only lib_for(cpu) loads it
+    src = open(os.path.join(REPO, "2048_q-learning_amd", "_native.py")).read()
+    assert src.count("load(HOST_LIB_PATH)") == 1 and "def host_lib" in src
 
 
 def test_product_never_imports_the_oracle():
@@ -147,6 +153,10 @@ def test_product_never_imports_the_oracle():
                     src = fh.read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
                 assert "liboracle" not in src and "q2048_oracle" not in src, f
+    for f in ("q2048_host.cpp",):                           # the CPU twin links nothing of the oracle either
+        with open(os.path.join(pkgdir, "csrc", f)) as fh:
+            src = fh.read()
+        assert "orc_" not in src and '#include "q2048_oracle' not in src, f
     for f in ("train.py", "q2048_amd.py"):
         path = os.path.join(REPO, f)
         if os.path.exists(path):
@@ -479,3 +489,50 @@ def test_stats_allreduce_object_single_process(pkg):
     assert a[0] == 0 and a[5] == 5 and b.tolist() == [1.0] * pkg._native.NSTAT_F
     with pytest.raises(RuntimeError):
         r.wait()
+
+
+def test_rank_pins_itself_to_the_numa_node_of_its_gpu(tmp_path):
+    """launch.pin_to_gpu_numa_node: sysfs reads + one sched_setaffinity, in the rank's own start (VERDICT r4 item
+    7a).  A fake sysfs tree: two CPU nodes and three GPUs in the KFD topology, GPUs 0 and 1 on NUMA node 0, GPU 2 on
+    node 1; *_VISIBLE_DEVICES re-maps the local rank; anything unknown leaves the process alone."""
+    spec = importlib.util.spec_from_file_location("q2048_launch_pin", os.path.join(REPO, "2048_q-learning_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) < 2:
+        pytest.skip("needs two CPUs")
+    half = len(mine) // 2
+    node_cpus = {0: mine[:half], 1: mine[half:]}
+    sysfs = tmp_path / "sys"
+    topo = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    gpus = [(0x0300, 0), (0x2300, 0), (0xa300, 1)]                     # location_id (bus << 8), NUMA node
+    for n in range(2):                                                  # CPU nodes of the topology come first
+        (topo / str(n)).mkdir(parents=True)
+        (topo / str(n) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for k, (loc, node) in enumerate(gpus):
+        d = topo / str(2 + k)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {loc}\ndomain 0\n")
+        pci = sysfs / "bus" / "pci" / "devices" / f"0000:{(loc >> 8) & 0xff:02x}:00.0"
+        pci.mkdir(parents=True)
+        (pci / "numa_node").write_text(f"{node}\n")
+    for node, cpus in node_cpus.items():
+        d = sysfs / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    assert launch.gpu_numa_nodes(str(sysfs)) == [0, 0, 1]
+    assert launch._cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    try:
+        assert launch.pin_to_gpu_numa_node(2, str(sysfs), environ={}) == (1, node_cpus[1])
+        assert sorted(os.sched_getaffinity(0)) == node_cpus[1]
+        os.sched_setaffinity(0, mine)
+        assert launch.pin_to_gpu_numa_node(0, str(sysfs), environ={"HIP_VISIBLE_DEVICES": "2,0"}) == (1, node_cpus[1])
+        os.sched_setaffinity(0, mine)
+        assert launch.pin_to_gpu_numa_node(1, str(sysfs), environ={"HIP_VISIBLE_DEVICES": "2,0"}) == (0, node_cpus[0])
+        os.sched_setaffinity(0, mine)
+        assert launch.pin_to_gpu_numa_node(0, str(sysfs), environ={"ROCR_VISIBLE_DEVICES": "GPU-abc"}) is None
+        assert launch.pin_to_gpu_numa_node(7, str(sysfs), environ={}) is None          # no such GPU
+        assert launch.pin_to_gpu_numa_node(0, str(tmp_path / "nothing"), environ={}) is None
+        assert sorted(os.sched_getaffinity(0)) == mine
+    finally:
+        os.sched_setaffinity(0, mine)

@@ -38,7 +38,7 @@ ON_CPU = [
     "test_row_tuple_single_env_matches_oracle", "test_episode_log_matches_reference_csv_rows",
     "test_legal_moves_mask", "test_encode_onehot_matches_reference_encoder", "test_tile_overflow_is_reported",
     "test_steps_counter_and_argument_checks", "test_deterministic_mode_batch_edges",
-    "test_no_learn_rollout_reads_but_never_writes",
+    "test_no_learn_rollout_reads_but_never_writes", "test_rollout_on_a_full_table_stays_bounded",
 ]
 for _name in ON_CPU:
     globals()[_name.replace("_on_device", "") + "_on_cpu"] = getattr(_par, _name)

@@ -160,12 +160,18 @@ def train_single(args, pkg):
 def train_batched(args, pkg):
     import torch
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and args.device != "cpu":
+        # a rank of a multi-GPU job sits on the CPUs next to its GPU (sysfs + sched_setaffinity, no GPU call yet)
+        pkg.launch.pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")))
     rank, local_rank, world = pkg.dist.init_process_group()
-    if ":" in args.device:
+    if args.device == "cpu":
+        dev = torch.device("cpu")
+    elif ":" in args.device:
         dev = torch.device(args.device)
     else:       # one rank = one GPU of the node (ranks share GPUs only in rehearsals on a smaller box)
         dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
-    torch.cuda.set_device(dev)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
     shard = pkg.weak_shard(args.num_envs, world, rank)
     B = shard.num_envs
     # the reference's q_table is a defaultdict (Agent/main.py:16): no capacity to choose.  Without
@@ -213,6 +219,12 @@ def train_batched(args, pkg):
                                      "Max Value", "Env"])
     # a resumed run goes on from the saved statistics: `epoch` epochs are done, epsilon has been
     # decayed that many times (Agent/main.py:109), the episode count is the restored one
+    if args.agent == "hash" and getattr(agent, "_growth", None) is not None:
+        # set-up, before the clock starts: the table the first growth moves into is mapped (a host thread of the
+        # library has been at it since the agent was built); every later one is mapped while the run goes on
+        ms = agent.wait_for_prefetch()
+        print(f"[rank {rank}] next table (2^{agent._growth.new_capacity_log2} slots) mapped in {ms:.0f} ms "
+              "before the run", flush=True)
     total_eps, epoch, launches, t0 = 0, epoch0, 0, time.time()
     if args.resume:
         reducer.start(agent.stats_i, agent.stats_f)
@@ -278,7 +290,8 @@ def _report_growths(agent, grown, rank) -> int:
         grown += 1
         print(f"[rank {rank}] table grew 2^{g['from_log2']} -> 2^{g['to_log2']} slots at step {g['at_step']}: "
               f"{g['rows']} rows moved in {g['ms']:.1f} ms on the stream"
-              + (f", host blocked {g['host_ms']:.1f} ms" if "host_ms" in g else " (host-synchronous)"), flush=True)
+              + (f", host blocked {g['host_ms']:.1f} ms (the table had been mapped in {g.get('prepare_ms', 0.0):.0f} ms "
+                 "by the library's host thread)" if "host_ms" in g else " (host-synchronous)"), flush=True)
     return grown
 
 
