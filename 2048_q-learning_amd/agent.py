@@ -322,7 +322,9 @@ class BatchedQLearningAgent:
                     stopping the loop.  It starts at 2**initial_capacity_log2 slots ("auto": 2^30 = 32 GiB when
                     that is at most an eighth of the free device memory, else the largest power of two that is,
                     at least 2^20) and, between launches, grows by a factor 2**growth_step_log2 (4) whenever the
-                    rows it holds pass `load_limit` (0.5) of its capacity: the next table is mapped by the
+                    rows it holds pass `load_limit` of its capacity (0.35: on a pre-filled table the step costs
+                    46 us at load 0.1, 57 at 0.36, 69 at 0.51, 87 at 0.61 -- profiles/r05_load_curve_prefilled.jsonl
+                    -- and memory is what the device has plenty of): the next table is mapped by the
                     library's host thread while rollouts go on (`prefetch_growth`: started as soon as the current
                     table is in place; else at half the limit), the move of the rows is queued on the stream
                     between two launches, the check (rows moved == rows the kernels created) and the release of
@@ -349,7 +351,7 @@ class BatchedQLearningAgent:
                  exploration_rate=1.0, exploration_min=0.01, capacity_log2: int = 24,
                  device="cuda", seed: int = 0, env_id0: int = 0, independent: bool = False,
                  strict_td: bool = False, board_size: int = 4, placement="auto", row_cache: bool = True,
-                 initial_capacity_log2="auto", max_capacity_log2: int | None = None, load_limit: float = 0.5,
+                 initial_capacity_log2="auto", max_capacity_log2: int | None = None, load_limit: float = 0.35,
                  growth_step_log2: int = 2, prefetch_growth: bool = True, async_growth: bool = True,
                  verify_growth: bool = False):
         self.device = _require_gpu(device)

@@ -1,7 +1,8 @@
 """The documents quote measured figures; the measurements live under profiles/.  Two rounds in a row a
 figure in the text survived its file's replacement.  This test ties them together:
 
-  * every profiles/rNN_* file named in DESIGN.md, README.md, INTEGRATION.md or profiles/README.md exists;
+  * every profiles/rNN_* file named in DESIGN.md, LABNOTES.md (rounds 1-4: DESIGN.md as it stood then), README.md,
+    INTEGRATION.md or profiles/README.md exists;
   * profiles/quoted_figures.json lists the figures the documents quote from JSON profiles -- document,
     file, path to the value, how it is formatted, and the phrase it appears in -- and every phrase,
     re-built from the FILE's value, must be in the document.  Editing a profile without its text, or a
@@ -14,7 +15,7 @@ import re
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md")]
+DOCS = ["DESIGN.md", "LABNOTES.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md")]
 MANIFEST = os.path.join(REPO, "profiles", "quoted_figures.json")
 
 

@@ -53,7 +53,7 @@ def parse_args(argv=None):
     p.add_argument("--capacity-log2", type=int, default=0,
                    help="Q-table slots = 2^n, fixed; 0 (default) = a table that grows like the reference's "
                         "defaultdict, without stopping the loop: it starts at --initial-capacity-log2 slots and "
-                        "grows fourfold whenever half of it is in use (the next table is mapped by a host thread "
+                        "grows fourfold whenever 0.35 of it is in use (the next table is mapped by a host thread "
                         "while the rollouts go on; the rows move between two launches)")
     p.add_argument("--initial-capacity-log2", type=int, default=0,
                    help="first capacity of the growing table; 0 (default) = 2^30 slots (32 GiB) when that is at most "
