@@ -4,11 +4,19 @@
  * statistics vector, which tests/test_gpu_parity.py compares with the Python host's.
  *
  *   usage: rollout_host <boards> <steps> <seed> <cap_log2> <eps> [steps per launch, default = steps]
+ *                       [grow before launch k, default = never]
  *
  * With more than one launch the rollouts go through q2048_fused_rollout_opts: the row every env
  * carries passes from launch to launch through a row cache (hipMalloc'd, zero-filled), and the
  * statistics are read from a host-side mirror (hipHostMalloc) that the last block of every launch
  * writes -- after the stream has been waited for, with no device-to-host copy.
+ *
+ * With the seventh argument the table is one that may GROW (q2048_table_reserve), like the reference's
+ * defaultdict (Agent/main.py:16), off the caller's critical path: the fourfold table starts being mapped by the
+ * library's host thread before the first launch (q2048_table_grow_begin), the move of the rows is queued on the
+ * stream between launch k - 1 and launch k (q2048_table_grow_commit: returns the new table at once), and the
+ * check and the hand-over of the old table happen after the last launch (q2048_table_grow_finish).  The
+ * statistics it prints are those of the run on a fixed table.
  */
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
@@ -29,6 +37,8 @@ int main(int argc, char **argv) {
   const int cap_log2 = argc > 4 ? atoi(argv[4]) : 22;
   const double eps = argc > 5 ? atof(argv[5]) : 0.95;
   const int64_t per_launch = argc > 6 && atoll(argv[6]) > 0 ? atoll(argv[6]) : steps;
+  const int64_t grow_at = argc > 7 ? atoll(argv[7]) : -1;
+  int cap_now = cap_log2;
 
   uint8_t *boards; q2048_aux *aux; q2048_slot *table; int64_t *stats_i; double *stats_f; uint32_t *status;
   CHECK_HIP(hipMalloc((void **)&boards, (size_t)B * 16));
@@ -36,7 +46,8 @@ int main(int argc, char **argv) {
   /* the table: any zero-filled device memory will do (hipMalloc + hipMemset); the library's own
    * allocator maps it from 2 MiB physical chunks, which this memory system serves 15-20 % faster
    * under scattered writes (include/q2048.h, q2048_table_alloc) */
-  CHECK_Q(q2048_table_alloc(cap_log2, 0, &table));
+  if (grow_at >= 0) CHECK_Q(q2048_table_reserve(cap_log2, cap_log2 + 2, 0, &table));
+  else CHECK_Q(q2048_table_alloc(cap_log2, 0, &table));
   CHECK_HIP(hipMalloc((void **)&stats_i, sizeof(int64_t) * Q2048_NSTAT_I));
   CHECK_HIP(hipMalloc((void **)&stats_f, sizeof(double) * Q2048_NSTAT_F));
   CHECK_HIP(hipMalloc((void **)&status, sizeof(uint32_t)));
@@ -66,10 +77,23 @@ int main(int argc, char **argv) {
     opts.size = (uint32_t)sizeof opts;
     opts.row_cache = cache; opts.stats_mirror = mirror; opts.mirror_ticket = ticket;
     uint64_t launches = 0;
+    q2048_growth *growth = NULL;
+    int64_t moved = -1;
+    if (grow_at >= 0) CHECK_Q(q2048_table_grow_begin(table, cap_now, cap_now + 2, &growth));   /* returns at once */
     for (int64_t done = 0; done < steps; done += per_launch, ++launches) {
       const int64_t k = steps - done < per_launch ? steps - done : per_launch;
-      CHECK_Q(q2048_fused_rollout_opts(boards, aux, table, cap_log2, B, 4, k, eps, 0.1, 0.99, seed, 0,
+      if (growth != NULL && (int64_t)launches == grow_at) {
+        /* the rows move between two launches, on the stream: nothing here waits for them.  Slots change with
+         * the table; the row cache notices by itself (its records carry a tag of the table they came from) */
+        CHECK_Q(q2048_table_grow_commit(growth, 1, 0, &table, NULL));
+        cap_now += 2;
+      }
+      CHECK_Q(q2048_fused_rollout_opts(boards, aux, table, cap_now, B, 4, k, eps, 0.1, 0.99, seed, 0,
                                        (uint32_t)done, 0, stats_i, stats_f, status, &opts, NULL));
+    }
+    if (growth != NULL) {
+      if (cap_now == cap_log2) CHECK_Q(q2048_table_grow_abort(growth));          /* never committed */
+      else CHECK_Q(q2048_table_grow_finish(growth, &moved));                     /* waits for the move, checks it */
     }
     CHECK_HIP(hipDeviceSynchronize());                    /* the one wait; the statistics are already here */
     if (mirror[Q2048_MIRROR_SEQ] != launches) { fprintf(stderr, "stale statistics mirror\n"); return 4; }
@@ -80,12 +104,13 @@ int main(int argc, char **argv) {
   CHECK_HIP(hipMemcpy(&st, status, sizeof st, hipMemcpyDeviceToHost));
   CHECK_HIP(hipMalloc((void **)&d_rows, sizeof(int64_t)));
   CHECK_HIP(hipMemset(d_rows, 0, sizeof(int64_t)));
-  CHECK_Q(q2048_table_count(table, cap_log2, d_rows, NULL));                    /* len(q_table) */
+  CHECK_Q(q2048_table_count(table, cap_now, d_rows, NULL));                     /* len(q_table) */
   CHECK_HIP(hipMemcpy(&rows, d_rows, sizeof rows, hipMemcpyDeviceToHost));
   uint8_t first[16];
   CHECK_HIP(hipMemcpy(first, boards, 16, hipMemcpyDeviceToHost));
 
-  printf("{\"steps\": %lld, \"episodes\": %lld, \"valid_moves\": %lld, \"score_sum\": %lld, "
+  printf("{\"capacity_log2\": %d, ", cap_now);
+  printf("\"steps\": %lld, \"episodes\": %lld, \"valid_moves\": %lld, \"score_sum\": %lld, "
          "\"inserts\": %lld, \"drops\": %lld, \"explored\": %lld, \"rows\": %lld, \"status\": %u, "
          "\"return_sum\": %.17g, \"board0\": [", (long long)si[Q2048_ST_STEPS],
          (long long)si[Q2048_ST_EPISODES], (long long)si[Q2048_ST_VALID], (long long)si[Q2048_ST_SCORE],

@@ -1697,12 +1697,15 @@ def test_c_host_program_drives_the_abi(pkg, tmp_path):
     st = agent.stats()
     # one launch through q2048_fused_rollout; then launches of 16 steps through q2048_fused_rollout_opts
     # with a row cache and the statistics read from the host-side mirror
-    for per_launch in (0, 16):
-        out = subprocess.run([exe, str(B), str(steps), str(seed), str(cap), str(eps), str(per_launch)], check=True,
-                             capture_output=True, text=True).stdout
+    # ... and the same launches on a table that grows fourfold before launch 2, off the critical path
+    # (q2048_table_reserve / _grow_begin / _grow_commit / _grow_finish from plain C): the same run
+    for per_launch, grow_at in ((0, None), (16, None), (16, 2)):
+        argv = [exe, str(B), str(steps), str(seed), str(cap), str(eps), str(per_launch)] + ([str(grow_at)] if grow_at is not None else [])
+        out = subprocess.run(argv, check=True, capture_output=True, text=True).stdout
         got = json.loads(out.strip().splitlines()[-1])
+        assert got["capacity_log2"] == cap + (2 if grow_at is not None else 0)
         for k in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "drops", "explored"):
-            assert got[k] == st[k], (per_launch, k)
+            assert got[k] == st[k], (per_launch, grow_at, k)
         assert got["rows"] == agent.table_size() and got["status"] == 0
         assert got["board0"] == env.boards[0].cpu().tolist()
         assert np.isclose(got["return_sum"], st["return_sum"], rtol=1e-9)

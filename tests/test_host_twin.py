@@ -120,3 +120,28 @@ def test_train_py_on_the_cpu_device_reproduces_g6(pkg, tmp_path):
         assert int(row[0]) == e and int(row[1]) == g["actions"][idx] and int(row[5]) == g["maxes"][idx]
         assert np.float32(float(row[3])) == np.float32(g["rewards"][idx])
         assert np.isclose(float(row[4]), g["ep_returns"][e], rtol=1e-5)
+
+
+def test_train_two_ranks_on_the_cpu_device_equal_one_rank(tmp_path):
+    """The N > 1 path end to end without a GPU: `train.py --device cpu --gpus 2` starts its own two ranks (launch.py),
+    they join a gloo group, each plays its contiguous shard of the global env ids on its own table replica, and the
+    only communication is the statistics reduction.  At epsilon = 1 (actions are draws) the job's rows -- episodes,
+    env-steps, mean return, mean score, best tile -- equal those of ONE rank playing all the ids; only the table
+    sizes differ (two replicas against one table)."""
+    import csv
+    import subprocess
+
+    common = ["--device", "cpu", "--epsilon", "1.0", "--max-steps", "64", "--steps-per-launch", "32", "--episodes", "50"]
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(REPO, "train.py"), *common, *a],   # noqa: E731
+                                    capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    p2 = run("--gpus", "2", "--num-envs", "2048", "--capacity-log2", "20", "--log", "two.csv")
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    assert (p2.stdout + p2.stderr).count("table check passed") == 2   # both ranks checked their replica (rank 1 reports on stderr)
+    p1 = run("--num-envs", "4096", "--capacity-log2", "21", "--log", "one.csv")
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    two, one = (list(csv.reader(open(tmp_path / f)))[1:] for f in ("two.csv", "one.csv"))
+    assert len(two) == len(one) == 2 and int(two[-1][2]) == 4096 * 64
+    for a, b in zip(two, one):
+        assert a[:4] == b[:4] and a[5:7] == b[5:7]               # epoch, episodes, env-steps, epsilon; score, best tile
+        assert abs(float(a[4]) - float(b[4])) <= 1e-3 * abs(float(b[4]))   # mean return: a float sum in another order
+        assert int(a[8]) == int(b[8]) == 0                       # no drops
