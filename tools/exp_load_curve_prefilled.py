@@ -21,6 +21,9 @@ spec.loader.exec_module(bench)
 
 cap = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+bits = [int(x, 0) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]     # experiment bits to alternate between
+if any(bits):
+    pkg._native.use_experiments_build()
 dev, B, S = "cuda:0", 1 << 20, 16
 env = pkg.BatchedGame2048Env(B, board_size=n, seed=0, device=dev)
 agent = pkg.BatchedQLearningAgent(1000, learning_rate=0.1, discount_factor=0.99, exploration_rate=0.95,
@@ -47,17 +50,20 @@ for target in (0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.3, 0.35, 0.4, 0.45, 0.5, 0.55,
         want -= k
     before = agent.recount_rows()
     agent.stats(reset=True)
-    times = []
-    for _ in range(3):
+    times, by_bits = [], {}
+    for r in range(3 * len(bits)):
+        agent.experiment_bits = bits[r % len(bits)]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         agent.fused_rollout(env, S)
         e1.record()
         e1.synchronize()
-        times.append(e0.elapsed_time(e1) * 1e3 / S)
+        by_bits.setdefault(hex(agent.experiment_bits), []).append(round(e0.elapsed_time(e1) * 1e3 / S, 2))
+        if r % len(bits) == 0:
+            times.append(e0.elapsed_time(e1) * 1e3 / S)
     st = agent.stats()
     after = agent.recount_rows()
     print(json.dumps({"cap_log2": cap, "board_size": n, "load_before": before / (1 << cap), "load_after": after / (1 << cap),
                       "us_per_step": [round(t, 2) for t in times], "median_us_per_step": round(sorted(times)[1], 2),
-                      "inserts_per_step": st["inserts"] / max(st["steps"], 1), "drops": st["drops"],
+                      "inserts_per_step": st["inserts"] / max(st["steps"], 1), "drops": st["drops"], "by_experiment_bits": by_bits,
                       "algorithmic_frac": (122 if n == 4 else 156) * B / (sorted(times)[1] * 1e-6) / 8e12}), flush=True)
