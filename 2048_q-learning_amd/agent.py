@@ -642,7 +642,8 @@ class BatchedQLearningAgent:
         commit_at = (0.25 if self.prefetch_growth else 1.0) * soft
         trigger = soft if at_max else (commit_at if self._growth is not None else min(0.5 * soft, commit_at))
         bound = self._rows_base + self._inserts_seen - self._inserts_at_base + 2 * (self._steps_unseen + env_steps)
-        if bound <= trigger or (self._growth is not None and bound <= hard and not self._growth.ready()):
+        if (bound <= trigger or (at_max and self._warned_full)      # (nothing left to decide at the largest capacity)
+                or (self._growth is not None and bound <= hard and not self._growth.ready())):
             self._steps_unseen += env_steps              # nothing to decide yet (or nothing to move into yet)
             return
         self._steps_launched -= env_steps                # (the read below must not count steps not yet queued)

@@ -322,35 +322,6 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
   return kNoSlot;
 }
 
-#ifdef Q2048_EXPERIMENTS
-// Measurement variant (experiment bit 15): the probe asks for TWO slots of the sequence at a time -- two
-// independent 16-byte loads, one wait -- and looks at them in order: one request more whenever the first slot
-// would have decided, one round trip less whenever it would not (a table at load 0.45: 45 % of the probes).
-__device__ __forceinline__ int64_t probe_find_wide(const q2048_slot* table, u64 mask, const Geo<4>::Key& key, Row& row,
-                                                   uint32_t maxp = kRolloutProbe) {
-  const Seq sq = seq_of(key_hash(key), mask);
-  row = Row{0.f, 0.f, 0.f, 0.f};
-  for (uint32_t p = 0, lim = probe_limit(mask, maxp); p < lim; p += 2) {
-    const u64 i0 = seq_slot(sq, p), i1 = seq_slot(sq, p + 1u);
-    u32x4 v0, v1;
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1) : "v"(&table[i0]), "v"(&table[i1]) : "memory");
-    const u64 k0 = (u64)v0.x | ((u64)v0.y << 32), k1 = (u64)v1.x | ((u64)v1.y << 32);
-    if (k0 == key.k0 || (k0 != 0ull && k1 == key.k0)) {
-      const bool first = k0 == key.k0;
-      const u64 i = first ? i0 : i1;
-      const u32x4 v = first ? v0 : v1;
-      const u64 hi = ld_u64(&table[i].q[2]);
-      row = Row{bits_f32(v.z), bits_f32(v.w), bits_f32((uint32_t)hi), bits_f32((uint32_t)(hi >> 32))};
-      return (int64_t)i;
-    }
-    if (k0 == 0ull) return ~(int64_t)i0;
-    if (k1 == 0ull) return ~(int64_t)i1;
-  }
-  return kNoSlot;
-}
-#endif
-
 // 5x5: {key, q0, q1} first; on a first-word match {q2, q3, second key word} -- two requests for
 // a hit instead of four (key, second word, two row halves).  A slot whose second word is still 0
 // is being created by its owner: wait for the word (`confirm`).
@@ -377,14 +348,6 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
   }
   return kNoSlot;
 }
-
-#ifdef Q2048_EXPERIMENTS
-__device__ __forceinline__ int64_t probe_find_wide(const q2048_slot* table, u64 mask, const Geo<5>::Key& key, Row& row,
-                                                   uint32_t maxp = kRolloutProbe) {
-  bool created;
-  return probe_find(table, mask, key, row, created, maxp);      // (4x4 only)
-}
-#endif
 
 // Find-or-create starting at slot `start` of the key's sequence (the hint of a failed probe_find,
 // or the home slot).  The first access is the claiming compare-and-swap itself: the slot was empty
@@ -1123,9 +1086,6 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
       int64_t slot_n = slot_s;
       if (!same) {
         if (x_noprobe) { qn = Row{0.f, 0.f, 0.f, 0.f}; slot_n = ~(int64_t)key_home(key_n, mask); }
-#ifdef Q2048_EXPERIMENTS
-        else if ((flags >> 15) & 1u) slot_n = probe_find_wide(table, mask, key_n, qn);
-#endif
         else slot_n = probe_find(table, mask, key_n, qn, ins_n);
       }
       const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
