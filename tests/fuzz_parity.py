@@ -15,12 +15,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2048_q-learning_amd")
 # FUZZ_PRODUCT=1: the SHIPPED library (its template instantiations, no experiment bits: deferred writes
 # always on); default: the measurement build, whose run-time write modes take bits 8..23 of `flags`
-PRODUCT = bool(os.environ.get("FUZZ_PRODUCT"))
+# FUZZ_DEVICE=cpu: the CPU twin (libq2048_host.so; no measurement build of it exists, so PRODUCT is implied) --
+# tests/test_host_twin.py runs a few trials of this in the CPU suite
+dev = os.environ.get("FUZZ_DEVICE", "cuda:0")
+PRODUCT = bool(os.environ.get("FUZZ_PRODUCT")) or dev == "cpu"
 if not PRODUCT:
     pkg._native.use_experiments_build()
 from oracle import oracle as O  # noqa: E402  (the checker)
 
-dev = "cuda:0"
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 cases = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):

@@ -145,3 +145,17 @@ def test_train_two_ranks_on_the_cpu_device_equal_one_rank(tmp_path):
         assert a[:4] == b[:4] and a[5:7] == b[5:7]               # epoch, episodes, env-steps, epsilon; score, best tile
         assert abs(float(a[4]) - float(b[4])) <= 1e-3 * abs(float(b[4]))   # mean return: a float sum in another order
         assert int(a[8]) == int(b[8]) == 0                       # no drops
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_parity_on_the_cpu_device(seed):
+    """tests/fuzz_parity.py (the confidence run of the GPU parity check: random geometry, batch, steps, epsilon,
+    learning rate, env profile, reset-shaping option, strict TD, random launch splits, the 4-call API mixed with the
+    fused rollout in mid-run; private rows, so every env is one reference agent) on the CPU twin: boards and aux
+    bit-exact, every Q row within 1e-5 of the oracle's, table size == the oracle's dict sizes."""
+    import subprocess
+
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tests", "fuzz_parity.py"), str(seed), "3"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, FUZZ_DEVICE="cpu"))
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    assert "3 cases passed" in p.stdout
