@@ -438,11 +438,24 @@ void q_lookup_impl_n(const q2048_slot* table, u64 mask, const uint8_t* boards, i
 }
 
 // ---- the fused rollout: Agent/main.py:91-101 + the reset of :81, `steps` times per env ----------------------------
+// A thread walks its range in GROUPS of kGroup envs, step by step: first every env of the group chooses, steps
+// and asks for the cache line its next state's row starts on (a prefetch), then every env does its table work.
+// One env at a time, every probe of s' is a DRAM miss the core sits through (~100 ns against ~100 ns of
+// arithmetic per step); sixteen at a time the misses overlap.  Per env nothing changes -- the same calls in the
+// same order on the same draws -- so B = 1 and private rows are the reference's loop as before; on a shared table
+// the interleaving of envs is a different schedule of the same Hogwild learner.
+constexpr int kGroup = 16;
 template <int N>
 void fused_rollout_n(uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int steps, double eps,
                      double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
                      int64_t* stats_i, double* stats_f, uint32_t* status, q2048_episode* log, int64_t log_cap,
                      uint64_t* log_count) {
+  using BoardT = typename Geo<N>::BoardT;
+  using Key = typename Geo<N>::Key;
+  struct Lane {
+    BoardT b; Aux a; Key key_s, key_n; Row q; int64_t slot_s; u64 salt; uint64_t id; double reward_sum;
+    StepOut o; int act; bool explored, same;
+  };
   const int env = env_bits(flags);
   const bool play_only = (flags & Q2048_FLAG_PLAY_ONLY) != 0, no_learn = (flags & Q2048_FLAG_NO_LEARN) != 0;
   const bool creates = !play_only && !no_learn, cas = (flags & Q2048_FLAG_TD_CAS) != 0;
@@ -453,80 +466,95 @@ void fused_rollout_n(uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mas
     Stats& st = sp[tid];
     TdCounters tdc;
     bool any_drop = false;
-    for (int64_t i = lo; i < hi; ++i) {
-      const uint64_t id = env_id0 + (uint64_t)i;
-      const u64 salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(id) : 0ull;
-      typename Geo<N>::BoardT b;
-      load_board(boards, i, b);
-      Aux a = ld_aux(aux, i);
-      auto key_s = state_key(b, salt, status);
-      // the row of the current state: read when the state is reached and carried (as the kernel carries it in
-      // registers); created at its first update (the defaultdict creates q_table[state] at :43)
-      Row q{0.f, 0.f, 0.f, 0.f};
-      int64_t slot_s = play_only ? kNoSlot : probe_find(table, mask, key_s, q);
-      double reward_sum = 0.0;
+    Lane lane[kGroup];
+    for (int64_t g0 = lo; g0 < hi; g0 += kGroup) {
+      const int n = (int)(hi - g0 < kGroup ? hi - g0 : kGroup);
+      for (int l = 0; l < n; ++l) {
+        Lane& L = lane[l];
+        const int64_t i = g0 + l;
+        L.id = env_id0 + (uint64_t)i;
+        L.salt = (flags & Q2048_FLAG_INDEPENDENT) ? lane_salt(L.id) : 0ull;
+        load_board(boards, i, L.b);
+        L.a = ld_aux(aux, i);
+        L.key_s = state_key(L.b, L.salt, status);
+        // the row of the current state: read when the state is reached and carried (as the kernel carries it in
+        // registers); created at its first update (the defaultdict creates q_table[state] at :43)
+        L.q = Row{0.f, 0.f, 0.f, 0.f};
+        L.slot_s = play_only ? kNoSlot : probe_find(table, mask, L.key_s, L.q);
+        L.reward_sum = 0.0;
+      }
       for (int t = 0; t < steps; ++t) {
-        const Draws x = draws(seed, id, ctr0 + (uint32_t)t, kStreamStep);
-        Draws y{0u, 0u, 0u, 0u};
-        if (env & kEnvDqn) y = draws(seed, id, ctr0 + (uint32_t)t, kStreamOver);
-        bool explored;
-        const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);       // :92
-        const StepOut o = env_step_any(env, b, a, act, x.x2, x.x3, y.x0, y.x1);              // :93
-        const auto key_n = state_key(b, salt, status);                                       // :94
-        const bool same = key_eq(key_n, key_s);
-        bool ins_s = false, ins_n = false;
-        if (slot_s < 0 && slot_s != kNoSlot && creates) slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
-        Row qn = q;                                                                          // q_table[next_state] (:41)
-        int64_t slot_n = slot_s;
-        if (!same) {
-          if (play_only) { qn = Row{0.f, 0.f, 0.f, 0.f}; slot_n = kNoSlot; }
-          else if (creates) slot_n = find_or_create(table, mask, key_n, qn, ins_n);
-          else slot_n = probe_find(table, mask, key_n, qn);
+        for (int l = 0; l < n; ++l) {                    // choose, step, ask for s'
+          Lane& L = lane[l];
+          const Draws x = draws(seed, L.id, ctr0 + (uint32_t)t, kStreamStep);
+          Draws y{0u, 0u, 0u, 0u};
+          if (env & kEnvDqn) y = draws(seed, L.id, ctr0 + (uint32_t)t, kStreamOver);
+          L.act = eps_greedy(eps, x.x0, x.x1, L.q.q0, L.q.q1, L.q.q2, L.q.q3, L.explored);       // :92
+          L.o = env_step_any(env, L.b, L.a, L.act, x.x2, x.x3, y.x0, y.x1);                      // :93
+          L.key_n = state_key(L.b, L.salt, status);                                              // :94
+          L.same = key_eq(L.key_n, L.key_s);
+          if (!L.same && !play_only) __builtin_prefetch(&table[key_hash(L.key_n) & mask], 1, 1);
         }
-        const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
-        const bool updated = slot_s >= 0;
-        float nq = 0.f;
-        if (updated) {                                                                       // :43, :99
-          if (no_learn) nq = td_value(row_get(q, act), o.reward, max_next, o.done != 0, lr, gamma);
-          else nq = td_update(&table[slot_s], act, row_get(q, act), o.reward, max_next, o.done != 0, lr, gamma, cas, tdc);
-        }
-        st.i[Q2048_ST_VALID] += o.valid != 0;
-        st.i[Q2048_ST_EXPLORE] += explored;
-        st.i[Q2048_ST_INSERTS] += (uint64_t)ins_s + (uint64_t)ins_n;
-        if (!updated && creates) { st.i[Q2048_ST_DROPS] += 1; any_drop = true; }
-        reward_sum += (double)o.reward;
-        if (o.done) {                                                                        // :103
-          st.i[Q2048_ST_EPISODES] += 1;
-          st.episode(a, o.max_log2);
-          if (log != nullptr) {                                                              // :59-62, :105
-            const uint64_t at = __atomic_fetch_add(log_count, (uint64_t)1, __ATOMIC_RELAXED);
-            if ((int64_t)at < log_cap) {
-              Row ql = q;
-              if (updated && !no_learn) row_set(ql, act, nq);
-              q2048_episode rec;
-              rec.env_id = id; rec.episode = a.episode; rec.action = (uint8_t)act;
-              rec.max_log2 = o.max_log2; rec.steps_lo = (uint16_t)(ctr0 + (uint32_t)t);
-              rec.reward = o.reward; rec.total_return = a.ep_return; rec.score = a.score;
-              rec.q[0] = ql.q0; rec.q[1] = ql.q1; rec.q[2] = ql.q2; rec.q[3] = ql.q3;
-              rec.reserved = 0u;
-              log[at] = rec;
-            }
+        for (int l = 0; l < n; ++l) {                    // the table: q_table[next_state], the TD write, the reset
+          Lane& L = lane[l];
+          const StepOut& o = L.o;
+          const int act = L.act;
+          bool ins_s = false, ins_n = false;
+          if (L.slot_s < 0 && L.slot_s != kNoSlot && creates) L.slot_s = probe_insert(table, mask, L.key_s, (u64)~L.slot_s, ins_s);
+          Row qn = L.q;                                                                          // q_table[next_state] (:41)
+          int64_t slot_n = L.slot_s;
+          if (!L.same) {
+            if (play_only) { qn = Row{0.f, 0.f, 0.f, 0.f}; slot_n = kNoSlot; }
+            else if (creates) slot_n = find_or_create(table, mask, L.key_n, qn, ins_n);
+            else slot_n = probe_find(table, mask, L.key_n, qn);
           }
-          begin_episode(b, a, seed, id, (env & kEnvResetShaping) != 0);                      // :81
-          key_s = state_key(b, salt, status);
-          q = Row{0.f, 0.f, 0.f, 0.f};
-          slot_s = play_only ? kNoSlot : probe_find(table, mask, key_s, q);
-        } else if (same) {             // invalid move: same state, its row just changed (:100)
-          if (updated && !no_learn) row_set(q, act, nq);
-          else if (!updated) slot_s = kNoSlot;
-        } else {
-          key_s = key_n; slot_s = slot_n; q = qn;                                            // :100
+          const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
+          const bool updated = L.slot_s >= 0;
+          float nq = 0.f;
+          if (updated) {                                                                         // :43, :99
+            if (no_learn) nq = td_value(row_get(L.q, act), o.reward, max_next, o.done != 0, lr, gamma);
+            else nq = td_update(&table[L.slot_s], act, row_get(L.q, act), o.reward, max_next, o.done != 0, lr, gamma, cas, tdc);
+          }
+          st.i[Q2048_ST_VALID] += o.valid != 0;
+          st.i[Q2048_ST_EXPLORE] += L.explored;
+          st.i[Q2048_ST_INSERTS] += (uint64_t)ins_s + (uint64_t)ins_n;
+          if (!updated && creates) { st.i[Q2048_ST_DROPS] += 1; any_drop = true; }
+          L.reward_sum += (double)o.reward;
+          if (o.done) {                                                                          // :103
+            st.i[Q2048_ST_EPISODES] += 1;
+            st.episode(L.a, o.max_log2);
+            if (log != nullptr) {                                                                // :59-62, :105
+              const uint64_t at = __atomic_fetch_add(log_count, (uint64_t)1, __ATOMIC_RELAXED);
+              if ((int64_t)at < log_cap) {
+                Row ql = L.q;
+                if (updated && !no_learn) row_set(ql, act, nq);
+                q2048_episode rec;
+                rec.env_id = L.id; rec.episode = L.a.episode; rec.action = (uint8_t)act;
+                rec.max_log2 = o.max_log2; rec.steps_lo = (uint16_t)(ctr0 + (uint32_t)t);
+                rec.reward = o.reward; rec.total_return = L.a.ep_return; rec.score = L.a.score;
+                rec.q[0] = ql.q0; rec.q[1] = ql.q1; rec.q[2] = ql.q2; rec.q[3] = ql.q3;
+                rec.reserved = 0u;
+                log[at] = rec;
+              }
+            }
+            begin_episode(L.b, L.a, seed, L.id, (env & kEnvResetShaping) != 0);                  // :81
+            L.key_s = state_key(L.b, L.salt, status);
+            L.q = Row{0.f, 0.f, 0.f, 0.f};
+            L.slot_s = play_only ? kNoSlot : probe_find(table, mask, L.key_s, L.q);
+          } else if (L.same) {           // invalid move: same state, its row just changed (:100)
+            if (updated && !no_learn) row_set(L.q, act, nq);
+            else if (!updated) L.slot_s = kNoSlot;
+          } else {
+            L.key_s = L.key_n; L.slot_s = slot_n; L.q = qn;                                      // :100
+          }
         }
       }
-      st.i[Q2048_ST_STEPS] += (uint64_t)steps;
-      st.f[Q2048_SF_REWARD] += reward_sum;
-      store_board(boards, i, b);
-      st_aux(aux, i, a);
+      for (int l = 0; l < n; ++l) {
+        st.i[Q2048_ST_STEPS] += (uint64_t)steps;
+        st.f[Q2048_SF_REWARD] += lane[l].reward_sum;
+        store_board(boards, g0 + l, lane[l].b);
+        st_aux(aux, g0 + l, lane[l].a);
+      }
     }
     st.i[Q2048_ST_CAS_RETRY] += tdc.retries;
     st.i[Q2048_ST_CAS_FALLBACK] += tdc.fallbacks;
