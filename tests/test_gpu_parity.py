@@ -2093,6 +2093,35 @@ def test_table_grows_like_the_reference_defaultdict(pkg, n):
     assert L.q2048_table_reserve(20, 19, 0, C.byref(out)) == -2 and L.q2048_table_reserve(20, 22, 12345, C.byref(out)) == -2
 
 
+def test_process_exit_with_a_growth_in_flight(tmp_path):
+    """A process may end at any point of a growth: while the library's host thread is still mapping the next table
+    (prefetch begun, never waited for), and with a committed growth nobody finished.  The thread is joined by an
+    atexit handler registered after the HIP runtime's own (so it runs first); nothing hangs, nothing crashes."""
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    code = """
+import importlib, sys
+sys.path.insert(0, %r)
+pkg = importlib.import_module("2048_q-learning_amd")
+mode = sys.argv[1]
+env = pkg.BatchedGame2048Env(65536, seed=1, device="cuda:0")
+agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2="auto", initial_capacity_log2=22,
+                                  max_capacity_log2=28, seed=1, device="cuda:0")
+assert agent._growth is not None                      # the 2^24-slot table is being mapped right now
+if mode == "committed":
+    for _ in range(6):
+        agent.fused_rollout(env, 8)                   # passes a quarter of the limit: the growth is committed ...
+    assert agent.capacity_log2 > 22 and agent._retiring is not None or agent.growths
+print("exiting", mode, flush=True)                    # ... and the process ends without finish / wait / free
+""" % REPO
+    for mode in ("preparing", "committed"):
+        p = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0 and "exiting " + mode in p.stdout, (mode, p.returncode, p.stderr[-1500:])
+
+
 def test_device_spanning_table_uses_64_bit_slot_indices(pkg):
     """A 2^32-slot table (128 GiB: what a run of 2^31 rows is given): rows land above slot 2^31 and
     above byte offset 2^36, every insert is a row, no drops."""

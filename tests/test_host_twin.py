@@ -159,3 +159,24 @@ def test_fuzz_parity_on_the_cpu_device(seed):
                        capture_output=True, text=True, timeout=900, env=dict(os.environ, FUZZ_DEVICE="cpu"))
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     assert "3 cases passed" in p.stdout
+
+
+def test_train_on_the_cpu_device_grows_its_table_like_a_fixed_one(tmp_path):
+    """`train.py --device cpu` without --capacity-log2: the host table grows (through the ABI alone: export, a larger
+    table, import) whenever the load limit is passed, with the growth's own check (rows moved == rows created) and the
+    end-of-run check; with one host thread the run is sequential, so the saved table equals the one of the same run
+    on a pre-sized table, row for row and bit for bit."""
+    import subprocess
+
+    common = ["--device", "cpu", "--num-envs", "1024", "--episodes", "2", "--steps-per-launch", "32", "--seed", "8"]
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(REPO, "train.py"), *common, *a], capture_output=True,  # noqa: E731
+                                    text=True, timeout=600, cwd=str(tmp_path), env=dict(os.environ, Q2048_HOST_THREADS="1"))
+    pg = run("--initial-capacity-log2", "14", "--save", "grown.pt", "--log", "g.csv")
+    assert pg.returncode == 0, pg.stderr[-2000:]
+    assert pg.stdout.count("table grew") >= 3 and "table check passed" in pg.stdout
+    pf = run("--capacity-log2", "21", "--save", "fixed.pt", "--log", "f.csv")
+    assert pf.returncode == 0, pf.stderr[-2000:]
+    a, b = (torch.load(tmp_path / f, map_location="cpu", weights_only=False) for f in ("grown.pt", "fixed.pt"))
+    oa, ob = np.argsort(a["keys"]), np.argsort(b["keys"])
+    assert len(a["keys"]) > 100000 and a["capacity_log2"] > 14
+    assert np.array_equal(a["keys"][oa], b["keys"][ob]) and np.array_equal(a["q"][oa], b["q"][ob])
