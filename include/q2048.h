@@ -12,9 +12,14 @@
  * Conventions
  *   - Plain pointers and sizes only.  Every data pointer is a DEVICE pointer (HIP); the caller
  *     owns all memory -- the library allocates nothing, with one exception the caller asks for by
- *     name: q2048_table_alloc / _reserve / _grow / _free (a Q-table mapped from 2 MiB physical
- *     chunks; host-synchronous).  `stream` is a hipStream_t (NULL = default stream).  All other
+ *     name: q2048_table_alloc / _reserve / _grow* / _trim / _free (a Q-table mapped from small physical
+ *     chunks, which may grow; _alloc, _reserve, _grow and _free are host-synchronous, _grow_begin and
+ *     _grow_commit return at once).  `stream` is a hipStream_t (NULL = default stream).  All other
  *     calls are asynchronous and stream-ordered: no host synchronisation inside.
+ *   - The same ABI exists for HOST memory: libq2048_host.so (csrc/q2048_host.cpp), compiled from the same
+ *     per-lane arithmetic and table layout -- every pointer is then a host pointer, `stream` is ignored and every
+ *     call is complete when it returns; the chunk allocator returns Q2048_ERR_UNSUPPORTED there.  It is a
+ *     device of its own ("cpu"), loaded only when asked for by name, never a fallback.
  *   - boards   uint8_t[B][16]: 4x4 board, row-major, log2 tiles (0 empty, k = tile 2^k), the
  *              device image of the reference's np.int64[4,4] raw-value board
  *              (Game2048_env.py:12).  16-byte aligned.
