@@ -180,3 +180,49 @@ def test_train_on_the_cpu_device_grows_its_table_like_a_fixed_one(tmp_path):
     oa, ob = np.argsort(a["keys"]), np.argsort(b["keys"])
     assert len(a["keys"]) > 100000 and a["capacity_log2"] > 14
     assert np.array_equal(a["keys"][oa], b["keys"][ob]) and np.array_equal(a["q"][oa], b["q"][ob])
+
+
+def test_c_host_program_drives_the_cpu_twin(pkg, tmp_path):
+    """examples/rollout_host_cpu.c: a plain-C host (malloc + q2048_* calls, no HIP, no Python) linked against
+    libq2048_host.so reproduces the Python host's run on device "cpu" -- the same ABI, on host memory.  One host
+    thread and epsilon = 0.3 on a SHARED table: the run is sequential, so every statistic, the row count and the
+    boards are equal exactly; in one call and cut into calls of 16 steps (the same cut on both sides)."""
+    import json
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc is not available")
+    exe = str(tmp_path / "rollout_host_cpu")
+    libdir = os.path.dirname(pkg._native.HOST_LIB_PATH)
+    subprocess.run([gcc, "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
+                    os.path.join(REPO, "examples", "rollout_host_cpu.c"), "-o", exe, "-L", libdir, "-lq2048_host",
+                    f"-Wl,-rpath,{libdir}"], check=True)
+    B, steps, seed, cap, eps = 3000, 70, 17, 20, 0.3
+    keep = os.environ.get("Q2048_HOST_THREADS")
+    os.environ["Q2048_HOST_THREADS"] = "1"
+    try:
+        for per_call in (0, 16):      # (on a shared table the cut is part of the schedule: the same cut on both sides)
+            env = pkg.BatchedGame2048Env(B, seed=seed, device="cpu")
+            agent = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.99, exploration_rate=eps,
+                                              capacity_log2=cap, seed=seed, device="cpu")
+            left = steps
+            while left > 0:
+                k = min(per_call or steps, left)
+                agent.fused_rollout(env, k)
+                left -= k
+            st = agent.stats()
+            out = subprocess.run([exe, str(B), str(steps), str(seed), str(cap), str(eps), str(per_call)], check=True,
+                                 capture_output=True, text=True, env=dict(os.environ, Q2048_HOST_THREADS="1")).stdout
+            got = json.loads(out.strip().splitlines()[-1])
+            for k in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "drops", "explored"):
+                assert got[k] == st[k], (per_call, k)
+            assert got["rows"] == agent.table_size() and got["status"] == 0
+            assert got["board0"] == env.boards[0].tolist()
+            assert np.isclose(got["return_sum"], st["return_sum"], rtol=1e-12)
+    finally:
+        if keep is None:
+            os.environ.pop("Q2048_HOST_THREADS", None)
+        else:
+            os.environ["Q2048_HOST_THREADS"] = keep
