@@ -27,8 +27,12 @@ def O():
 
 @pytest.fixture(scope="session")
 def pkg():
-    """The product package (directory name is not a Python identifier)."""
-    return importlib.import_module("2048_q-learning_amd")
+    """The product package (directory name is not a Python identifier).  A native library that is missing or older
+    than its sources is built first (what __graft_entry__.build() does): a fresh checkout must not fail on that."""
+    mod = importlib.import_module("2048_q-learning_amd")
+    mod._native.build()            # no-op when csrc/libq2048_hip.so is newer than its sources
+    mod._native.build_host()       # the CPU twin, likewise
+    return mod
 
 
 def load_npz(name):
