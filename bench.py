@@ -236,13 +236,9 @@ def prefill(torch, agent, load: float, seed: int) -> int:
         agent.import_rows_device(keys.view(-1) if words == 1 else keys, zeros[:n])
         want -= n
     del zeros
-    if agent.check_status() & pkg_status_full():
+    if agent.check_status() & 4:                         # Q2048_STATUS_TABLE_FULL
         raise SystemExit("prefill: the table dropped rows")
     return agent.recount_rows()
-
-
-def pkg_status_full() -> int:
-    return 4   # Q2048_STATUS_TABLE_FULL
 
 
 def cpu_baseline_product_core(pkg, torch, args, seconds: float) -> dict:

@@ -2462,3 +2462,19 @@ def test_train_self_launched_two_ranks_share_one_gpu(tmp_path):
     assert rows and int(rows[-1]["Epoch"]) == 2
     assert int(rows[-1]["Episodes"]) >= 2 * 8192                      # both shards' episodes
     assert int(rows[-1]["Env-Steps"]) % (8192 * 32) == 0 and int(rows[-1]["Drops"]) == 0
+    # the same job on the default, GROWING tables: every rank grows its own replica off the critical path (its own
+    # host thread of the library, its own prefetch) and checks it at the end; epsilon = 1 makes the trajectories
+    # independent of the tables, so the all-reduced rows equal the fixed-capacity run's
+    log2 = tmp_path / "train_growing.csv"
+    # (epsilon_min = 2/3 makes the schedule's first phase flat at 1.0: Agent/main.py:28,46-48)
+    common = ["--gpus", "2", "--num-envs", "4096", "--episodes", "1000", "--steps-per-launch", "32", "--report-every", "4",
+              "--epsilon", "1.0", "--epsilon-min", "0.6666666666666666", "--max-steps", "256"]
+    runs = {}
+    for name, extra in (("fixed", ["--capacity-log2", "24"]), ("growing", ["--initial-capacity-log2", "14"])):
+        out = tmp_path / f"{name}.csv"
+        p = subprocess.run([sys.executable, os.path.join(REPO, "train.py"), *common, *extra, "--log", str(out)],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+        assert p.returncode == 0, p.stderr[-3000:]
+        runs[name] = (p.stdout + p.stderr, [r[:3] + r[4:7] for r in list(csv.reader(open(out)))[1:]])
+    assert runs["growing"][0].count("table check passed") == 2 and runs["growing"][0].count("table grew") >= 4
+    assert runs["growing"][1] == runs["fixed"][1] and len(runs["fixed"][1]) >= 2
