@@ -2093,6 +2093,30 @@ def test_table_grows_like_the_reference_defaultdict(pkg, n):
     assert L.q2048_table_reserve(20, 19, 0, C.byref(out)) == -2 and L.q2048_table_reserve(20, 22, 12345, C.byref(out)) == -2
 
 
+def test_growing_table_falls_back_to_a_fixed_one_when_it_cannot_be_mapped(pkg, monkeypatch):
+    """`capacity_log2="auto"` on a stack without the virtual-memory API, or without room for the first
+    table, used to raise out of the constructor (and `train.py`'s default with it).  The chunk allocator is made to
+    fail here: the agent warns, takes ONE fixed plain table and trains on it; a table that is not growable refuses
+    `grow_table`."""
+    agent_mod = __import__("importlib").import_module("2048_q-learning_amd.agent")
+
+    def refuse(self, *a, **kw):
+        raise pkg._native.NativeError("q2048_table_reserve: device memory could not be reserved, created or mapped (code -8)")
+
+    monkeypatch.setattr(agent_mod._ChunkedTable, "__init__", refuse)
+    monkeypatch.setattr(agent_mod, "auto_capacity_log2", lambda *a, **kw: 22)          # (keep the fallback table small)
+    with pytest.warns(UserWarning, match="could not be mapped"):
+        agent = pkg.BatchedQLearningAgent(100, exploration_rate=0.5, capacity_log2="auto", seed=2, device=DEV)
+    assert not agent.growable and agent.capacity_log2 == 22 and agent.placement["mode"] == "plain"
+    assert "growable_failed" in agent.placement and agent._growth is None
+    env = pkg.BatchedGame2048Env(4096, seed=2, device=DEV)
+    agent.fused_rollout(env, 32)
+    st = agent.stats()
+    assert st["steps"] == 4096 * 32 and st["inserts"] == agent.table_size() > 0 and st["drops"] == 0
+    with pytest.raises(RuntimeError):
+        agent.grow_table()
+
+
 def test_process_exit_with_a_growth_in_flight(tmp_path):
     """A process may end at any point of a growth: while the library's host thread is still mapping the next table
     (prefetch begun, never waited for), and with a committed growth nobody finished.  The thread is joined by an
