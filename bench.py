@@ -255,7 +255,7 @@ def cpu_baseline_product_core(pkg, torch, args, seconds: float) -> dict:
     try:
         for T in sorted({1, min(16, cores), min(32, cores), max(1, cores // 4), cores}):
             os.environ["Q2048_HOST_THREADS"] = str(T)
-            B, steps = 16384 * T, 24
+            B, steps = min(16384 * T, 1 << 21), 24            # (at most 2 Mi boards: an 8 GiB host table)
             env = pkg.BatchedGame2048Env(B, seed=args.seed, device="cpu")
             cap = max(20, int(np.ceil(np.log2(2.0 * B * 64))))
             agent = pkg.BatchedQLearningAgent(1000, learning_rate=args.alpha, discount_factor=args.gamma,
