@@ -26,7 +26,7 @@ HOST_DEPS = ["q2048_host.cpp", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.
 SOURCES = ["q2048_kernels.hip"]
 DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc"]
 
-OK, PENDING, ERR_BUSY = 0, 1, -10
+OK, PENDING, ERR_ALLOC, ERR_BUSY = 0, 1, -8, -10
 GROW_VERIFY_COUNT = 1
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
 FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
@@ -51,7 +51,11 @@ class RolloutOpts(C.Structure):
 
 
 class NativeError(RuntimeError):
-    """A q2048_* entry point returned an error code."""
+    """A q2048_* entry point returned an error code (`code`: the Q2048_ERR_* value, when known)."""
+
+    def __init__(self, message="", code=None):
+        super().__init__(message)
+        self.code = code
 
 
 def hipcc_path() -> str:
@@ -278,4 +282,4 @@ def claim_timeouts(L: C.CDLL | None = None) -> int:
 def check(code: int, what: str) -> None:
     if code != OK:
         L = _lib or _host_lib or lib()
-        raise NativeError(f"{what}: {L.q2048_strerror(code).decode()} (code {code})")
+        raise NativeError(f"{what}: {L.q2048_strerror(code).decode()} (code {code})", code)

@@ -166,7 +166,7 @@ class _Growth:
 
     def __init__(self, owner: _ChunkedTable, new_capacity_log2: int):
         self.owner, self.new_capacity_log2 = owner, new_capacity_log2
-        self.handle, self.bigger, self.info = C.c_void_p(), None, {}
+        self.handle, self.bigger, self.info, self.prepared_ok = C.c_void_p(), None, {}, None
         with torch.cuda.device(owner.device):
             N.check(N.lib().q2048_table_grow_begin(owner.ptr, owner.capacity_log2, new_capacity_log2,
                                                    C.byref(self.handle)), "q2048_table_grow_begin")
@@ -179,7 +179,7 @@ class _Growth:
         """q2048_table_grow_wait: blocks until the bigger table is mapped; returns the ms the host thread spent on
         it (a failure is left for `commit` to report)."""
         ms = C.c_double(0.0)
-        N.lib().q2048_table_grow_wait(self.handle, C.byref(ms))
+        self.prepared_ok = N.lib().q2048_table_grow_wait(self.handle, C.byref(ms)) == N.OK
         return float(ms.value)
 
     def commit(self, key_words: int, stream, verify_count: bool = False) -> _ChunkedTable:
@@ -693,9 +693,16 @@ class BatchedQLearningAgent:
         with torch.cuda.device(self.device):              # (raises with the old table intact and still self.table)
             try:
                 bigger = g.commit(1 if self.board_size == 4 else 2, _stream(self.device), self.verify_growth)
-            except N.NativeError:
+            except N.NativeError as exc:
                 self._growth = None
-                raise
+                if exc.code != N.ERR_ALLOC:
+                    raise
+                # the device has no room for the next table (other tenants, a smaller card): this capacity is the
+                # largest from here on -- the run goes on, and `_room_for` warns when the load passes the limit
+                self.max_capacity_log2 = self.capacity_log2
+                warnings.warn(f"the Q-table cannot grow beyond 2^{self.capacity_log2} slots: the table of "
+                              f"2^{g.new_capacity_log2} slots could not be mapped ({exc})")
+                return
         ev[1].record()
         self.table = bigger.tensor(self.device)           # every launch from here on takes the new table
         self.table._q2048_owner = bigger

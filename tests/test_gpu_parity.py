@@ -2117,6 +2117,33 @@ def test_growing_table_falls_back_to_a_fixed_one_when_it_cannot_be_mapped(pkg, m
         agent.grow_table()
 
 
+def test_growth_that_finds_no_room_caps_the_table_instead_of_ending_the_run(pkg, monkeypatch):
+    """The device has no room for the next table (another tenant, a smaller card): the preparation fails, the commit
+    reports Q2048_ERR_ALLOC, and the run goes on on the table it has -- that capacity is the largest from then on, a
+    warning says so -- instead of an exception out of `fused_rollout` in mid-training."""
+    agent_mod = __import__("importlib").import_module("2048_q-learning_amd.agent")
+    N = pkg._native
+    real_commit = agent_mod._Growth.commit
+
+    def no_room(self, *a, **kw):
+        self.abort()                                       # (give the prepared table back: the failure is simulated)
+        raise N.NativeError("q2048_table_grow_commit: device memory could not be reserved, created or mapped (code -8)", N.ERR_ALLOC)
+
+    env = pkg.BatchedGame2048Env(1 << 16, seed=4, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2="auto", initial_capacity_log2=18,
+                                      max_capacity_log2=24, seed=4, device=DEV)
+    monkeypatch.setattr(agent_mod._Growth, "commit", no_room)
+    with pytest.warns(UserWarning, match="cannot grow beyond"):
+        for _ in range(4):
+            agent.fused_rollout(env, 8)
+    assert agent.capacity_log2 == 18 == agent.max_capacity_log2 and agent._growth is None and not agent.growths
+    monkeypatch.setattr(agent_mod._Growth, "commit", real_commit)
+    agent.fused_rollout(env, 8)                            # and on it goes, on the table it has
+    st = agent.stats()
+    assert st["steps"] == (1 << 16) * 40 and agent.table_size() == st["inserts"]
+    assert agent.verify_table()["capacity_log2"] == 18
+
+
 def test_process_exit_with_a_growth_in_flight(tmp_path):
     """A process may end at any point of a growth: while the library's host thread is still mapping the next table
     (prefetch begun, never waited for), and with a committed growth nobody finished.  The thread is joined by an

@@ -223,8 +223,9 @@ def train_batched(args, pkg):
         # set-up, before the clock starts: the table the first growth moves into is mapped (a host thread of the
         # library has been at it since the agent was built); every later one is mapped while the run goes on
         ms = agent.wait_for_prefetch()
-        print(f"[rank {rank}] next table (2^{agent._growth.new_capacity_log2} slots) mapped in {ms:.0f} ms "
-              "before the run", flush=True)
+        print(f"[rank {rank}] next table (2^{agent._growth.new_capacity_log2} slots) "
+              + (f"mapped in {ms:.0f} ms before the run" if agent._growth.prepared_ok else
+                 f"could NOT be mapped ({ms:.0f} ms): the run stays on 2^{agent.capacity_log2} slots"), flush=True)
     total_eps, epoch, launches, t0 = 0, epoch0, 0, time.time()
     if args.resume:
         reducer.start(agent.stats_i, agent.stats_f)
