@@ -30,8 +30,8 @@ OK, PENDING, ERR_ALLOC, ERR_BUSY = 0, 1, -8, -10
 GROW_VERIFY_COUNT = 1
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
 FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
-FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY, FLAG_NO_LEARN = 8, 16, 32, 64
-ABI_VERSION = 5
+FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY, FLAG_NO_LEARN, FLAG_NO_NEW_ROWS = 8, 16, 32, 64, 128
+ABI_VERSION = 6
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
 ST_HIST0, NSTAT_I = 8, 32
 ST_HIST_BINS, ST_CAS_FALLBACK = 23, 31

@@ -335,6 +335,17 @@ class BatchedQLearningAgent:
                     first table the agent falls back to ONE fixed plain table (a warning says so).
                     `async_growth=False`: the host-synchronous q2048_table_grow of round 4 instead (same result,
                     bit for bit: tested).
+    freeze_load     what a table does when it CANNOT grow any more (a fixed `capacity_log2`, or a growing one at its
+                    largest capacity) -- SURVEY 7.3's "stop inserting and count drops", the device counterpart of a
+                    defaultdict (Agent/main.py:16) that has no limit: once the table holds `freeze_load` of its
+                    capacity in rows (checked between launches with the kernels' own insert counter, so the load ends
+                    within one launch of the limit), every launch carries Q2048_FLAG_NO_NEW_ROWS: rows that exist keep
+                    learning, a state without a row reads as the zero row the defaultdict would have created, is not
+                    created, and its update is dropped and counted (stats['drops']); a warning says so once and
+                    `frozen` is True from then on.  Default 0.6: at 1 Mi boards the step on a table frozen there costs
+                    what the growing table's costs at its load limit, where a table driven to load 1.0 takes 12.9 ms
+                    per step (profiles/r05_claim_first_ab.jsonl).  None: never freeze -- the table fills up, probes of
+                    absent states walk up to 2^10 slots, and updates that find no slot are dropped (status TABLE_FULL).
     independent     every env owns private rows (keys salted with its global id): B independent
                     learners in one table, exactly B reference agents side by side.
     placement       how the table is allocated (`place_table`): "auto", "chunks", "plain" or a count
@@ -353,7 +364,7 @@ class BatchedQLearningAgent:
                  strict_td: bool = False, board_size: int = 4, placement="auto", row_cache: bool = True,
                  initial_capacity_log2="auto", max_capacity_log2: int | None = None, load_limit: float = 0.35,
                  growth_step_log2: int = 2, prefetch_growth: bool = True, async_growth: bool = True,
-                 verify_growth: bool = False):
+                 verify_growth: bool = False, freeze_load: "float | None" = 0.6):
         self.device = _require_gpu(device)
         self._L = N.lib_for(self.device)
         self.on_gpu = self.device.type == "cuda"
@@ -367,6 +378,10 @@ class BatchedQLearningAgent:
         self.growth_step_log2, self.prefetch_growth = max(1, int(growth_step_log2)), bool(prefetch_growth)
         self.async_growth, self.verify_growth = bool(async_growth), bool(verify_growth)
         self._growth = self._retiring = None      # a growth being prepared / one committed and not yet finished
+        if freeze_load is not None and not 0.05 <= float(freeze_load) <= 0.95:
+            raise ValueError("freeze_load must be in [0.05, 0.95], or None (never freeze)")
+        self.freeze_load = None if freeze_load is None else float(freeze_load)
+        self.frozen, self.frozen_at = False, None  # the key set is closed (Q2048_FLAG_NO_NEW_ROWS on every launch)
         if self.growable:
             if not 0.05 <= self.load_limit <= 0.9:
                 raise ValueError("load_limit must be in [0.05, 0.9]")
@@ -492,7 +507,7 @@ class BatchedQLearningAgent:
         N.check(self._L.q2048_q_update_cached(
             _ptr(self.table), self.capacity_log2, _ptr(boards), _ptr(actions), _ptr(reward),
             _ptr(next_boards), _ptr(done), B, self.board_size, float(self.lr), float(self.gamma), self.env_id0,
-            self.flags, _ptr(self._cache(B)), _ptr(self.stats_i), _ptr(self.status), _stream(self.device)),
+            self._learn_flags(), _ptr(self._cache(B)), _ptr(self.stats_i), _ptr(self.status), _stream(self.device)),
             "q_update")
 
     def q_values(self, boards: torch.Tensor, env_id: int | None = None,
@@ -544,8 +559,8 @@ class BatchedQLearningAgent:
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, env.num_envs,
             self.board_size, int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed,
             self.env_id0, self.ctr & 0xFFFFFFFF,
-            self.flags | self.experiment_bits | env.env_flags | (N.FLAG_PLAY_ONLY if play_only else 0) |
-            (0 if learn else N.FLAG_NO_LEARN),
+            (self._learn_flags() if learn and not play_only else self.flags) | self.experiment_bits | env.env_flags |
+            (N.FLAG_PLAY_ONLY if play_only else 0) | (0 if learn else N.FLAG_NO_LEARN),
             _ptr(self.stats_i), _ptr(self.stats_f), _ptr(self.status), C.byref(opts), _stream(self.device)),
             "fused_rollout")
         if env.num_envs > 0 and int(steps) > 0:
@@ -588,7 +603,7 @@ class BatchedQLearningAgent:
         N.check(L.q2048_det_rollout(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, B, self.board_size,
             int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed, self.env_id0,
-            self.ctr & 0xFFFFFFFF, self.flags | env.env_flags | self.experiment_bits, _ptr(self.stats_i),
+            self.ctr & 0xFFFFFFFF, self._learn_flags() | env.env_flags | self.experiment_bits, _ptr(self.stats_i),
             _ptr(self.stats_f), _ptr(self.status), base, need, _stream(self.device)), "det_rollout")
         env.ctr += int(steps)
         self.ctr += int(steps)
@@ -607,8 +622,14 @@ class BatchedQLearningAgent:
         self._inserts_seen, self._steps_at_read, self._steps_unseen = seen, self._steps_launched, 0
         return self._rows_base + seen - self._inserts_at_base
 
-    def _rebase_rows(self, rows: int) -> None:
+    def _learn_flags(self) -> int:
+        """The agent's flags for a call that may create rows: with the key set closed, Q2048_FLAG_NO_NEW_ROWS."""
+        return self.flags | (N.FLAG_NO_NEW_ROWS if self.frozen else 0)
+
+    def _rebase_rows(self, rows: int, table_changed: bool = True) -> None:
         """`rows` rows are in the table now (a count, an import): the new base of the row bookkeeping."""
+        if table_changed:
+            self.frozen = False                           # (decided again by the next `_room_for`)
         self._rows_base = int(rows)
         self._inserts_at_base = self._inserts_seen = self._cumulative_inserts()
         self._steps_at_read, self._steps_unseen = self._steps_launched, 0
@@ -626,24 +647,26 @@ class BatchedQLearningAgent:
             fewer rows there are the cheaper the move); while it is not ready the rollouts go on on the old table
             until the worst case (two rows per env-step) would pass load_limit + 0.25 (at most 0.85), and only
             then wait for it.
-        A table at its largest capacity warns once when it passes the limit."""
+        A table that cannot grow (a fixed capacity, or the largest one) closes its key set at `freeze_load`
+        (`_freeze_check`); with freeze_load=None it warns once when it passes the load limit."""
         env_steps = int(env_steps)
         self._steps_launched += env_steps
-        if not self.growable:
+        if self.frozen:
             return
         if self._retiring is not None and self._retiring.ready():
             self._finish_retiring()
+        if not self.growable or self.capacity_log2 >= self.max_capacity_log2:
+            self._freeze_check(env_steps)
+            return
         cap = 1 << self.capacity_log2
         soft, hard = self.load_limit * cap, min(0.85, self.load_limit + 0.25) * cap
-        at_max = self.capacity_log2 >= self.max_capacity_log2
         # the load at which this call has something to do: a prefetched table is moved into as soon as it is ready
         # and a quarter of the limit is in use (the fewer rows, the cheaper the move; the memory is committed
         # anyway); without prefetch the mapping begins at half the limit and the move waits for the limit
         commit_at = (0.25 if self.prefetch_growth else 1.0) * soft
-        trigger = soft if at_max else (commit_at if self._growth is not None else min(0.5 * soft, commit_at))
+        trigger = commit_at if self._growth is not None else min(0.5 * soft, commit_at)
         bound = self._rows_base + self._inserts_seen - self._inserts_at_base + 2 * (self._steps_unseen + env_steps)
-        if (bound <= trigger or (at_max and self._warned_full)      # (nothing left to decide at the largest capacity)
-                or (self._growth is not None and bound <= hard and not self._growth.ready())):
+        if bound <= trigger or (self._growth is not None and bound <= hard and not self._growth.ready()):
             self._steps_unseen += env_steps              # nothing to decide yet (or nothing to move into yet)
             return
         self._steps_launched -= env_steps                # (the read below must not count steps not yet queued)
@@ -655,12 +678,8 @@ class BatchedQLearningAgent:
             soft, hard = self.load_limit * cap, min(0.85, self.load_limit + 0.25) * cap
             commit_at = (0.25 if self.prefetch_growth else 1.0) * soft
             expect, worst = rows + self._row_rate * env_steps, rows + 2 * env_steps
-            if self.capacity_log2 >= self.max_capacity_log2:
-                if rows > soft and not self._warned_full:
-                    self._warned_full = True
-                    warnings.warn(f"the Q-table is at its largest capacity (2^{self.capacity_log2} slots) and holds "
-                                  f"{rows} rows (load {rows / cap:.2f} > {self.load_limit}): lookups slow down, and "
-                                  "updates that find no slot within the probe limit are dropped and counted")
+            if self.capacity_log2 >= self.max_capacity_log2:   # (the last growth was just committed, or one failed)
+                self._freeze_decide(rows)
                 return
             if not self.async_growth:
                 if expect > soft or worst > hard:
@@ -673,6 +692,43 @@ class BatchedQLearningAgent:
                 self._commit_growth(rows)
                 continue                                  # (a launch larger than the new table's room: again)
             return
+
+    def _freeze_check(self, env_steps: int) -> None:
+        """A table that cannot grow, about to take `env_steps` more env-steps.  Free while the host-side bound (two
+        new rows per env-step launched since the last read) stays below the threshold; else one synchronising 8-byte
+        read of the kernels' insert counter and the decision (`_freeze_decide`)."""
+        cap = 1 << self.capacity_log2
+        limit = (self.freeze_load if self.freeze_load is not None else self.load_limit) * cap
+        bound = self._rows_base + self._inserts_seen - self._inserts_at_base + 2 * (self._steps_unseen + env_steps)
+        if bound <= limit or (self.freeze_load is None and self._warned_full):
+            self._steps_unseen += env_steps
+            return
+        self._steps_launched -= env_steps                # (the read must not count steps not yet queued)
+        rows = self._rows_exact()
+        self._steps_launched += env_steps
+        self._steps_unseen = env_steps
+        self._freeze_decide(rows)
+
+    def _freeze_decide(self, rows: int) -> None:
+        """`rows` rows (exact, at this stream point) in a table that cannot grow: close the key set at freeze_load."""
+        cap = 1 << self.capacity_log2
+        if self.freeze_load is None:
+            if rows > self.load_limit * cap and not self._warned_full:
+                self._warned_full = True
+                warnings.warn(f"the Q-table is at its largest capacity (2^{self.capacity_log2} slots) and holds "
+                              f"{rows} rows (load {rows / cap:.2f} > {self.load_limit}) with freeze_load=None: lookups "
+                              "slow down, and updates that find no slot within the probe limit are dropped and counted")
+            return
+        if rows < self.freeze_load * cap:
+            return
+        self.frozen = True
+        self.frozen_at = {"rows": int(rows), "capacity_log2": self.capacity_log2, "load": rows / cap, "at_step": self.ctr}
+        if not self._warned_full:
+            self._warned_full = True
+            warnings.warn(f"the Q-table cannot grow beyond 2^{self.capacity_log2} slots and holds {rows} rows (load "
+                          f"{rows / cap:.2f} >= freeze_load {self.freeze_load}): it takes no new rows from here on -- rows "
+                          "that exist keep learning, a state without a row reads as zeros (the defaultdict's fresh row) "
+                          "and its updates are dropped and counted (stats()['drops'])")
 
     def _begin_growth(self) -> None:
         owner = getattr(self.table, "_q2048_owner", None)
@@ -828,7 +884,7 @@ class BatchedQLearningAgent:
             raise RuntimeError(f"Q-table self-check failed: {rows} occupied slots, expected {expect} "
                                f"({self._rows_base} counted earlier + {expect - self._rows_base} created since); "
                                f"{timeouts} 5x5 claim time-outs")
-        self._rebase_rows(rows)
+        self._rebase_rows(rows, table_changed=False)
         return {"rows": rows, "capacity_log2": self.capacity_log2, "load": rows / float(1 << self.capacity_log2)}
 
     # -- statistics / table access ---------------------------------------------------------
@@ -938,8 +994,10 @@ class BatchedQLearningAgent:
         while self.growable and rows * 2 > (1 << self.capacity_log2) and self.capacity_log2 < self.max_capacity_log2:
             self.grow_table(min(self.max_capacity_log2,
                                 max(self.capacity_log2 + 1, int(np.ceil(np.log2(2.0 * rows))))))
-        if rows * 2 > (1 << self.capacity_log2):
-            raise ValueError("table too small for the checkpoint (load factor would exceed 0.5)")
+        # (a table that can grow is taken to load <= 0.5; one that cannot takes what a frozen table of its capacity
+        # holds -- freeze_load plus a launch -- and the import's probe limit of 2^14 slots places rows up to load 0.93)
+        if rows > 0.9 * (1 << self.capacity_log2):
+            raise ValueError("table too small for the checkpoint (load factor would exceed 0.9)")
         tk = torch.from_numpy(keys.view(np.int64)).to(self.device)
         tq = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.device)
         status = torch.zeros(1, dtype=torch.int32, device=self.device)   # this call's own word: the

@@ -156,11 +156,12 @@ inline int64_t probe_insert(q2048_slot* table, u64 mask, const Key& key, u64 sta
   return kNoSlot;
 }
 // find, then create where the probe ended: the defaultdict's q_table[state] (Agent/main.py:16,41-43)
+// (`create` = false: Q2048_FLAG_NO_NEW_ROWS -- the key set is closed, an absent state stays absent and reads as zeros)
 template <class Key>
-inline int64_t find_or_create(q2048_slot* table, u64 mask, const Key& key, Row& row, bool& inserted) {
+inline int64_t find_or_create(q2048_slot* table, u64 mask, const Key& key, Row& row, bool& inserted, bool create = true) {
   inserted = false;
   int64_t slot = probe_find(table, mask, key, row);
-  if (slot < 0 && slot != kNoSlot) {
+  if (slot < 0 && slot != kNoSlot && create) {
     slot = probe_insert(table, mask, key, (u64)~slot, inserted);
     if (slot >= 0 && !inserted) row = ld_row(&table[slot]);   // another thread created it meanwhile
   }
@@ -242,7 +243,8 @@ inline int check_table(const void* table, int cap_log2) {
   return Q2048_OK;
 }
 constexpr uint32_t kAbiFlags = Q2048_FLAG_INDEPENDENT | Q2048_FLAG_SINGLE_ENV | Q2048_FLAG_TD_CAS | Q2048_FLAG_ENV_DQN |
-                               Q2048_FLAG_RESET_SHAPING | Q2048_FLAG_PLAY_ONLY | Q2048_FLAG_NO_LEARN;
+                               Q2048_FLAG_RESET_SHAPING | Q2048_FLAG_PLAY_ONLY | Q2048_FLAG_NO_LEARN |
+                               Q2048_FLAG_NO_NEW_ROWS;
 inline int check_flags(uint32_t flags, uint32_t refused = 0u) {
   return ((flags & ~kAbiFlags) || (flags & refused)) ? Q2048_ERR_FLAGS : Q2048_OK;
 }
@@ -387,7 +389,7 @@ void q_update_impl_n(q2048_slot* table, u64 mask, const uint8_t* s, const uint8_
   const int T = threads_for(B);
   std::vector<Stats> parts((size_t)T);
   Stats* sp = parts.data();
-  const bool cas = (flags & Q2048_FLAG_TD_CAS) != 0;
+  const bool cas = (flags & Q2048_FLAG_TD_CAS) != 0, create = (flags & Q2048_FLAG_NO_NEW_ROWS) == 0;
   const int used = parallel_ranges(B, [=](int64_t lo, int64_t hi, int t) {
     Stats& st = sp[t];
     TdCounters tdc;
@@ -402,16 +404,16 @@ void q_update_impl_n(q2048_slot* table, u64 mask, const uint8_t* s, const uint8_
       const auto key_n = state_key(b_n, salt, status);
       Row rs, rn;
       bool ins_s = false, ins_n = false;
-      const int64_t slot = find_or_create(table, mask, key_s, rs, ins_s);     // q_table[state] (:43)
+      const int64_t slot = find_or_create(table, mask, key_s, rs, ins_s, create);     // q_table[state] (:43)
       rn = rs;
-      if (!key_eq(key_n, key_s)) find_or_create(table, mask, key_n, rn, ins_n);   // q_table[next_state] (:41)
+      if (!key_eq(key_n, key_s)) find_or_create(table, mask, key_n, rn, ins_n, create);   // q_table[next_state] (:41)
       st.i[Q2048_ST_INSERTS] += (uint64_t)ins_s + (uint64_t)ins_n;
       if (slot >= 0) {
         td_update(&table[slot], act, row_get(rs, act), reward[i], max4(rn.q0, rn.q1, rn.q2, rn.q3), done[i] != 0, lr,
                   gamma, cas, tdc);
       } else {
         st.i[Q2048_ST_DROPS] += 1;
-        status_or(status, Q2048_STATUS_TABLE_FULL);
+        if (create || slot == kNoSlot) status_or(status, Q2048_STATUS_TABLE_FULL);   // (closed key set: the caller's policy)
       }
     }
     st.i[Q2048_ST_CAS_RETRY] += tdc.retries;
@@ -458,7 +460,8 @@ void fused_rollout_n(uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mas
   };
   const int env = env_bits(flags);
   const bool play_only = (flags & Q2048_FLAG_PLAY_ONLY) != 0, no_learn = (flags & Q2048_FLAG_NO_LEARN) != 0;
-  const bool creates = !play_only && !no_learn, cas = (flags & Q2048_FLAG_TD_CAS) != 0;
+  const bool learns = !play_only && !no_learn, frozen = (flags & Q2048_FLAG_NO_NEW_ROWS) != 0;
+  const bool creates = learns && !frozen, cas = (flags & Q2048_FLAG_TD_CAS) != 0;
   const int T = threads_for(B);
   std::vector<Stats> parts((size_t)T);
   Stats* sp = parts.data();
@@ -518,7 +521,7 @@ void fused_rollout_n(uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mas
           st.i[Q2048_ST_VALID] += o.valid != 0;
           st.i[Q2048_ST_EXPLORE] += L.explored;
           st.i[Q2048_ST_INSERTS] += (uint64_t)ins_s + (uint64_t)ins_n;
-          if (!updated && creates) { st.i[Q2048_ST_DROPS] += 1; any_drop = true; }
+          if (!updated && learns) { st.i[Q2048_ST_DROPS] += 1; any_drop = any_drop || !frozen; }
           L.reward_sum += (double)o.reward;
           if (o.done) {                                                                          // :103
             st.i[Q2048_ST_EPISODES] += 1;
@@ -570,6 +573,7 @@ void det_rollout_n(uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask,
                    double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
                    int64_t* stats_i, double* stats_f, uint32_t* status) {
   const int env = env_bits(flags);
+  const bool create = (flags & Q2048_FLAG_NO_NEW_ROWS) == 0;
   std::vector<int64_t> cell((size_t)B);          // slot * 4 + action, or -1 (dropped)
   std::vector<double> target((size_t)B);
   int64_t* cp = cell.data();
@@ -593,13 +597,13 @@ void det_rollout_n(uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask,
         if (env & kEnvDqn) y = draws(seed, id, ctr, kStreamOver);
         Row q, qn;
         bool ins_s = false, ins_n = false, explored;
-        const int64_t slot_s = find_or_create(table, mask, key_s, q, ins_s);
+        const int64_t slot_s = find_or_create(table, mask, key_s, q, ins_s, create);
         const bool dropped = slot_s < 0;
-        if (dropped) { q = Row{0.f, 0.f, 0.f, 0.f}; status_or(status, Q2048_STATUS_TABLE_FULL); }
+        if (dropped) { q = Row{0.f, 0.f, 0.f, 0.f}; if (create || slot_s == kNoSlot) status_or(status, Q2048_STATUS_TABLE_FULL); }
         const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);       // :92
         const StepOut o = env_step_any(env, b, a, act, x.x2, x.x3, y.x0, y.x1);              // :93
         const auto key_n = state_key(b, salt, status);
-        find_or_create(table, mask, key_n, qn, ins_n);                                       // :41
+        find_or_create(table, mask, key_n, qn, ins_n, create);                               // :41
         cp[i] = dropped ? -1 : slot_s * 4 + act;
         tp[i] = td_target(o.reward, max4(qn.q0, qn.q1, qn.q2, qn.q3), o.done != 0, gamma);   // :42
         st.i[Q2048_ST_STEPS] += 1;

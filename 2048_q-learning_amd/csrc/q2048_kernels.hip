@@ -920,6 +920,9 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
     const bool is_done = done[i] != 0;
     bool ins_n = false, ins_s = false, dropped = false;
     TdCounters tdc{0u, 0u};
+    // Q2048_FLAG_NO_NEW_ROWS: the key set is closed -- absent states read as zeros, nothing is claimed, an update
+    // of a state without a row is dropped and counted (the caller's policy: no TABLE_FULL)
+    const bool frozen = (flags & Q2048_FLAG_NO_NEW_ROWS) != 0u;
     if (act > 3) {
       atomicOr(status, Q2048_STATUS_BAD_ACTION);
     } else {
@@ -933,7 +936,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
       int64_t slot = kNoSlot;
       if (cache == nullptr || !cache_get(cache, i, key_s, cache_tag(table, mask), rs, slot)) {
         slot = probe_find(table, mask, key_s, rs, ins_s);
-        if (slot < 0 && slot != kNoSlot) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
+        if (slot < 0 && slot != kNoSlot && !frozen) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
       }
       // q_table[next_state] (:41), created when absent as well; an invalid move stays on the row of s
       // The claim of an absent s' is issued here and its answer read after the TD write of s, which
@@ -943,7 +946,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
       Claim claim{0ull, 0ull, false};
       if (!same) {
         slot_n = probe_find(table, mask, key_n, rn, ins_n);
-        slot_n = claim_issue(table, mask, slot_n, key_n, claim, ins_n);
+        if (!frozen) slot_n = claim_issue(table, mask, slot_n, key_n, claim, ins_n);
       }
       const float max_next = max4(rn.q0, rn.q1, rn.q2, rn.q3);
       if (slot >= 0) {
@@ -952,7 +955,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
         if (same) row_set(rn, act, nq);                  // the row it stays on just changed (:100)
       } else {
         dropped = true;
-        atomicOr(status, Q2048_STATUS_TABLE_FULL);
+        if (!frozen || slot == kNoSlot) atomicOr(status, Q2048_STATUS_TABLE_FULL);
       }
       bool ins_c = false;
       slot_n = claim_resolve(table, mask, key_n, claim, slot_n, ins_c);
@@ -992,7 +995,10 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
 // MODE: what the launch does with the table -- a template parameter, so the step loop carries no
 // run-time mode tests (kModeLearn: plain-store TD; kModeCas: Q2048_FLAG_TD_CAS; kModeEval:
 // Q2048_FLAG_NO_LEARN; play-only is an ENV bit).  Experiment builds select write modes at run time.
-constexpr int kModeLearn = 0, kModeCas = 1, kModeEval = 2;
+// kModeFrozen (a bit, with kModeLearn or kModeCas): Q2048_FLAG_NO_NEW_ROWS -- the key set is closed: no claim is ever
+// issued (the Claim pipeline, the insert of an episode's opening state and of a terminal state compile away), a
+// state without a row reads as zeros and its update is dropped and counted.
+constexpr int kModeLearn = 0, kModeCas = 1, kModeEval = 2, kModeFrozen = 4;
 // Lanes per workgroup of the fused rollout: 512 for batches that fill the chip more than twice over at that
 // size (>= 786 432 boards), 256 below.  Nine alternating pairs of the driver's command at 1 Mi boards: 47.2 us
 // per step against 48.3 (8 of 9 pairs; 5x5: 64.4 against 66.4; profiles/r04_block512_*.txt) -- half as many
@@ -1039,14 +1045,15 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     // (epsilon-greedy over the stored values), nothing is created or written
     constexpr bool play_only = (ENV & kEnvPlayOnly) != 0;
     constexpr bool no_learn = MODE == kModeEval;
+    constexpr bool frozen = (MODE & kModeFrozen) != 0;
 #ifdef Q2048_EXPERIMENTS   // bits 8..11 write mode, 12 no row creation, 13 no next-state probe, 14 no deferral, 16..23 CAS attempts
     const uint32_t td_mode = no_learn ? (uint32_t)kTdNone : td_mode_of(flags);
-    const bool x_noclaim = ((flags >> 12) & 1u) || play_only || no_learn, x_noprobe = ((flags >> 13) & 1u) || play_only;
+    const bool x_noclaim = ((flags >> 12) & 1u) || play_only || no_learn || frozen, x_noprobe = ((flags >> 13) & 1u) || play_only;
     const bool may_defer = td_mode == kTdStorePlain && !((flags >> 14) & 1u);
     const int max_cas = ((flags >> 16) & 0xffu) ? (int)((flags >> 16) & 0xffu) : kMaxCas;
 #else
-    constexpr uint32_t td_mode = no_learn ? kTdNone : (MODE == kModeCas ? kTdCas : kTdStorePlain);
-    constexpr bool x_noclaim = play_only || no_learn, x_noprobe = play_only;
+    constexpr uint32_t td_mode = no_learn ? kTdNone : ((MODE & kModeCas) ? kTdCas : kTdStorePlain);
+    constexpr bool x_noclaim = play_only || no_learn || frozen, x_noprobe = play_only;
     constexpr bool may_defer = td_mode == kTdStorePlain;
     constexpr int max_cas = kMaxCas;
 #endif
@@ -1156,7 +1163,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     // row does not exist yet -- an episode began on the last step -- leaves an empty record)
     if (!play_only && cache != nullptr) cache_put(cache, i, key_s, cache_tag(table, mask), q, slot_s);
 
-    if (n_drop) atomicOr(status, Q2048_STATUS_TABLE_FULL);
+    if (n_drop && !frozen) atomicOr(status, Q2048_STATUS_TABLE_FULL);   // (frozen: dropping is the caller's policy)
     if (tdc.retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)tdc.retries);
     if (tdc.fallbacks) atomicAdd(&bs.i[Q2048_ST_CAS_FALLBACK], (u64)tdc.fallbacks);
     atomicAdd(&bs.f[Q2048_SF_REWARD], reward_sum);
@@ -1225,6 +1232,7 @@ __global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
     if constexpr ((ENV & kEnvDqn) != 0) y = draws(seed, id, ctr, kStreamOver);
     Row q{0.f, 0.f, 0.f, 0.f}, qn;
     bool ins_s = false, ins_n = false, dropped = false;
+    const bool frozen = (flags & Q2048_FLAG_NO_NEW_ROWS) != 0u;   // closed key set: nothing is created, absent = dropped
     // s is the s' of the step before unless an episode began in between: its slot was found then
     // (rows never move), so there is no probe -- and the row itself is needed by greedy lanes only
     // (at epsilon 0.95: one scattered request per step less for 19 lanes of 20)
@@ -1235,15 +1243,15 @@ __global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
       if (!(draw_uniform(x.x0) < eps)) q = ld_row(&table[slot_s]);
     } else {
       slot_s = probe_find(table, mask, key_s, q, ins_s);
-      if (slot_s < 0 && slot_s != kNoSlot) slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
-      if (slot_s < 0) { dropped = true; atomicOr(status, Q2048_STATUS_TABLE_FULL); }
+      if (slot_s < 0 && slot_s != kNoSlot && !frozen) slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
+      if (slot_s < 0) { dropped = true; if (!frozen || slot_s == kNoSlot) atomicOr(status, Q2048_STATUS_TABLE_FULL); }
     }
     bool explored;
     const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);     // main.py:92
     const StepOut o = env_step_profile<ENV>(b, a, act, x.x2, x.x3, y.x0, y.x1);         // :93
     const auto key_n = state_key(b, salt, status);
     int64_t slot_n = probe_find(table, mask, key_n, qn, ins_n);                         // :41
-    if (slot_n < 0 && slot_n != kNoSlot) slot_n = probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
+    if (slot_n < 0 && slot_n != kNoSlot && !frozen) slot_n = probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
     carry[i] = (!o.done && slot_n >= 0 && (u64)slot_n < (u64)kNoCarry) ? (uint32_t)slot_n : kNoCarry;
     // the group of this update: (slot of s, action), sorted by a hash of (s, action).  The sort is
     // stable and this array is in env order, so env order survives without an index
@@ -1937,7 +1945,7 @@ inline int check_table(const void* table, int cap_log2) {
   hipLaunchKernelGGL((k_fused_rollout<NN, E, M, BLK>), dim3((unsigned)(((B) + (BLK) - 1) / (BLK))), dim3(BLK), 0, \
                      (hipStream_t)(stream), __VA_ARGS__)
 #define Q2048_LAUNCH_FUSED_CASE(E, M, n, B, stream, ...)                                          \
-  case (E) * 4 + (M):                                                                             \
+  case (E) * 8 + (M):                                                                             \
     if ((n) == 4) {                                                                               \
       if ((B) >= kFusedBigBatch) Q2048_LAUNCH_FUSED_ONE(4, E, M, kFusedBlockBig, B, stream, __VA_ARGS__);     \
       else Q2048_LAUNCH_FUSED_ONE(4, E, M, kFusedBlockSmall, B, stream, __VA_ARGS__);             \
@@ -1949,9 +1957,11 @@ inline int check_table(const void* table, int cap_log2) {
 #define Q2048_LAUNCH_FUSED_ENV(E, n, B, stream, ...)                                              \
   Q2048_LAUNCH_FUSED_CASE(E, kModeLearn, n, B, stream, __VA_ARGS__)                               \
   Q2048_LAUNCH_FUSED_CASE(E, kModeCas, n, B, stream, __VA_ARGS__)                                 \
-  Q2048_LAUNCH_FUSED_CASE(E, kModeEval, n, B, stream, __VA_ARGS__)
+  Q2048_LAUNCH_FUSED_CASE(E, kModeEval, n, B, stream, __VA_ARGS__)                                \
+  Q2048_LAUNCH_FUSED_CASE(E, kModeFrozen, n, B, stream, __VA_ARGS__)                              \
+  Q2048_LAUNCH_FUSED_CASE(E, kModeFrozen + kModeCas, n, B, stream, __VA_ARGS__)
 #define Q2048_LAUNCH_FUSED(flags, n, B, stream, ...)                                              \
-  switch (env_bits(flags) * 4 + fused_mode(flags)) {                                              \
+  switch (env_bits(flags) * 8 + fused_mode(flags)) {                                              \
     Q2048_LAUNCH_FUSED_ENV(0, n, B, stream, __VA_ARGS__)                                          \
     Q2048_LAUNCH_FUSED_ENV(1, n, B, stream, __VA_ARGS__)                                          \
     Q2048_LAUNCH_FUSED_ENV(2, n, B, stream, __VA_ARGS__)                                          \
@@ -1967,12 +1977,13 @@ inline int env_bits(uint32_t flags) {
 }
 inline int fused_mode(uint32_t flags) {   // play-only launches touch no table: one instantiation
   if (flags & Q2048_FLAG_PLAY_ONLY) return kModeLearn;
-  return (flags & Q2048_FLAG_NO_LEARN) ? kModeEval : ((flags & Q2048_FLAG_TD_CAS) ? kModeCas : kModeLearn);
+  if (flags & Q2048_FLAG_NO_LEARN) return kModeEval;   // (evaluation creates nothing anyway)
+  return ((flags & Q2048_FLAG_TD_CAS) ? kModeCas : kModeLearn) | ((flags & Q2048_FLAG_NO_NEW_ROWS) ? kModeFrozen : 0);
 }
 // flag bits outside the ABI are an argument error (experiment builds also take bits 8..23)
 constexpr uint32_t kAbiFlags = Q2048_FLAG_INDEPENDENT | Q2048_FLAG_SINGLE_ENV | Q2048_FLAG_TD_CAS |
                                Q2048_FLAG_ENV_DQN | Q2048_FLAG_RESET_SHAPING | Q2048_FLAG_PLAY_ONLY |
-                               Q2048_FLAG_NO_LEARN;
+                               Q2048_FLAG_NO_LEARN | Q2048_FLAG_NO_NEW_ROWS;
 inline int check_flags(uint32_t flags, uint32_t refused = 0u) {
   uint32_t allowed = kAbiFlags;
 #ifdef Q2048_EXPERIMENTS

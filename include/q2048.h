@@ -49,12 +49,13 @@
 extern "C" {
 #endif
 
-#define Q2048_ABI_VERSION 5 /* 3: flag bits outside the ABI are refused (Q2048_ERR_FLAGS), Q2048_ST_CAS_FALLBACK,
+#define Q2048_ABI_VERSION 6 /* 3: flag bits outside the ABI are refused (Q2048_ERR_FLAGS), Q2048_ST_CAS_FALLBACK,
                                deterministic step sorted by a hash of (state, action)
                                4: q2048_fused_rollout_opts (row cache + statistics mirror of the fused
                                rollout), q2048_table_grow, q2048_table_alloc verifies its zero fill
                                5: growth off the caller's critical path (q2048_table_grow_begin / _poll /
-                               _commit / _finish / _abort) */
+                               _commit / _finish / _abort)
+                               6: Q2048_FLAG_NO_NEW_ROWS (a table that has stopped taking new rows) */
 
 /* return codes */
 #define Q2048_OK 0
@@ -111,6 +112,23 @@ extern "C" {
                                      written.  What the `evaluate.py` the reference's README lists
                                      (README.md:52, no such file in the repository) has to do */
 
+#define Q2048_FLAG_NO_NEW_ROWS 128u /* the table's key set is CLOSED for this call (a table that cannot
+                                     grow any more "stops inserting and counts drops").  The reference's q_table is a
+                                     defaultdict (Agent/main.py:16) that creates a row at every lookup of an unseen
+                                     state (:38, :41, :43) and grows until the host swaps; a device table has a last
+                                     capacity, and filling it to the brim makes every probe of an absent state walk
+                                     hundreds of slots (12.9 ms per 2^20-board step at load 1.0 against 48 us).  With
+                                     this flag
+                                       - a state that has a row is read and updated exactly as without it;
+                                       - a state without one reads as the zero row the defaultdict would have created
+                                         (same greedy action, same bootstrap value 0), and NO row is created for it;
+                                       - an update of Q[s][a] whose state has no row is dropped and counted in
+                                         Q2048_ST_DROPS; Q2048_STATUS_TABLE_FULL is NOT raised (the caller asked).
+                                     q2048_q_update / _cached, q2048_fused_rollout*, q2048_det_rollout; ignored by the
+                                     entry points that never create rows (choose, lookup, env, NO_LEARN, PLAY_ONLY).
+                                     The host decides when: BatchedQLearningAgent(freeze_load=0.6) sets it on every
+                                     launch once a table at its largest capacity holds that share of rows */
+
 /* per-env state, Game2048_env.__init__ (Game2048_env.py:81-95) + episode bookkeeping */
 typedef struct q2048_aux {
   int32_t score;       /* env.score (:84); zeroed by reset (:190) */
@@ -153,7 +171,7 @@ enum {
   Q2048_ST_VALID = 2,    /* board-changing moves */
   Q2048_ST_SCORE = 3,    /* sum of env.score over finished episodes */
   Q2048_ST_INSERTS = 4,  /* Q rows created */
-  Q2048_ST_DROPS = 5,    /* updates dropped (probe limit) */
+  Q2048_ST_DROPS = 5,    /* updates dropped: no slot within the probe limit, or (Q2048_FLAG_NO_NEW_ROWS) no row */
   Q2048_ST_EXPLORE = 6,  /* epsilon branch taken */
   Q2048_ST_CAS_RETRY = 7,/* TD compare-and-swap retries (same (s,a) updated concurrently) */
   Q2048_ST_HIST0 = 8,    /* max-tile histogram of finished episodes, log2 0..22 (saturating) */
@@ -290,8 +308,8 @@ int q2048_q_lookup(const q2048_slot *table, int cap_log2, const uint8_t *boards,
  * aux and the Q row of the current state stay in registers between steps.  Step t uses the
  * draws of counter ctr0 + t.  Bit-identical to calling q_choose / env_step / q_update /
  * env_reset(done) `steps` times whenever no two lanes share a state.
- * flags: Q2048_FLAG_INDEPENDENT, _TD_CAS, _ENV_DQN, _RESET_SHAPING, _PLAY_ONLY, _NO_LEARN; any bit
- * outside the Q2048_FLAG_* set is Q2048_ERR_FLAGS (all entry points). */
+ * flags: Q2048_FLAG_INDEPENDENT, _TD_CAS, _ENV_DQN, _RESET_SHAPING, _PLAY_ONLY, _NO_LEARN, _NO_NEW_ROWS; any
+ * bit outside the Q2048_FLAG_* set is Q2048_ERR_FLAGS (all entry points). */
 int q2048_fused_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2,
                         int64_t B, int n, int64_t steps, double eps, double lr, double gamma,
                         uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
@@ -365,7 +383,7 @@ int q2048_fused_rollout_opts(uint8_t *boards, q2048_aux *aux, q2048_slot *table,
  * alone: the sort key depends on the state and the action, never on which slot a racing insert
  * won, and every group is folded by the same sequence of operations whatever its size.  `steps`
  * steps per call, draws of counter ctr0 + t.  flags: Q2048_FLAG_INDEPENDENT, _ENV_DQN,
- * _RESET_SHAPING; _TD_CAS is ignored; _NO_LEARN and _PLAY_ONLY are refused (Q2048_ERR_FLAGS: there
+ * _RESET_SHAPING, _NO_NEW_ROWS; _TD_CAS is ignored; _NO_LEARN and _PLAY_ONLY are refused (Q2048_ERR_FLAGS: there
  * is no evaluation form of this step, and learning anyway would be the wrong answer).
  * `workspace`: caller-owned device scratch of q2048_det_workspace_bytes(B, cap_log2) bytes
  * (about 36 bytes per env; host arithmetic, needs no device), 256-byte aligned (B < 2^31).  It

@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
         "orc_agent_q": (C.c_int, [vp, u8p, f64p]),
         "orc_agent_size": (C.c_int64, [vp]),
         "orc_agent_set_storage_f32": (None, [vp, C.c_int]),
+        "orc_agent_set_frozen": (None, [vp, C.c_int]),
+        "orc_agent_drops": (C.c_int64, [vp]),
         "orc_agent_dump": (C.c_int64, [vp, u8p, f64p, C.c_int64]),
         "orc_envs_init": (None, [vp, C.c_int64, C.c_int, C.c_uint64, C.c_uint64]),
         "orc_rollout": (None, [vp, C.c_int64, vp, C.c_int64, C.c_uint64, C.c_uint64,
@@ -296,6 +298,15 @@ class Agent:
 
     def reserve(self, rows: int):
         lib().orc_agent_reserve(self._h, int(rows))
+
+    def freeze(self, on: bool = True):
+        """Closed key set (orc_agent_t.frozen; NOT the reference -- the build's policy for a table that cannot
+        grow, Q2048_FLAG_NO_NEW_ROWS): absent states read as zeros and are not created, their updates drop."""
+        lib().orc_agent_set_frozen(self._h, int(bool(on)))
+
+    @property
+    def drops(self) -> int:
+        return int(lib().orc_agent_drops(self._h))
 
     def _key(self, board):
         b = np.zeros(MAXCELLS, dtype=np.uint8)

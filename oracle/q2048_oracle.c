@@ -437,6 +437,16 @@ static int orc_argmax4(const double *q, int n) { /* np.argmax: first maximum */
   return b;
 }
 
+/* q_table[state]: the defaultdict's lookup (creates the row, Agent/main.py:16) -- or, with the closed key
+ * set (orc_agent_t.frozen; not in the reference), the row if it exists and else a zero row that is nobody's */
+static orc_row_t *orc_row_of(orc_agent_t *a, const uint8_t *key) {
+  static const orc_row_t zero_row = {{0}, {0.0, 0.0, 0.0, 0.0}, 0};   /* read only: callers write rows they
+                                                                         got from orc_qtable_get alone */
+  if (!a->frozen) return orc_qtable_get(a->q, key, NULL);
+  orc_row_t *r = orc_qtable_find(a->q, key);
+  return r ? r : (orc_row_t *)&zero_row;
+}
+
 /* QLearningAgent.choose_action (:34-38) */
 int orc_agent_choose(orc_agent_t *a, const uint8_t *board, uint32_t draw_eps,
                      uint32_t draw_act, int *explored) {
@@ -447,7 +457,7 @@ int orc_agent_choose(orc_agent_t *a, const uint8_t *board, uint32_t draw_eps,
   if (explored) *explored = 0;
   uint8_t key[ORC_MAXCELLS];
   orc_key_of(a, board, key);
-  return orc_argmax4(orc_qtable_get(a->q, key, NULL)->q, a->action_space); /* :38 */
+  return orc_argmax4(orc_row_of(a, key)->q, a->action_space);              /* :38 */
 }
 
 /* QLearningAgent.update_q_value (:40-43) */
@@ -456,10 +466,11 @@ void orc_agent_update(orc_agent_t *a, const uint8_t *s, int action, double rewar
   uint8_t k1[ORC_MAXCELLS], k2[ORC_MAXCELLS];
   orc_key_of(a, s, k1);
   orc_key_of(a, s2, k2);
-  orc_row_t *rn = orc_qtable_get(a->q, k2, NULL);
+  orc_row_t *rn = orc_row_of(a, k2);
   int best_next = orc_argmax4(rn->q, a->action_space);                     /* :41 */
   double qn = rn->q[best_next];
   double target = reward + (a->gamma * qn * (double)(1 - (done ? 1 : 0))); /* :42 */
+  if (a->frozen && !orc_qtable_find(a->q, k1)) { a->drops += 1; return; }  /* closed key set: no row, no update */
   orc_row_t *rs = orc_qtable_get(a->q, k1, NULL); /* may grow: rn is dead from here */
   rs->q[action] += a->lr * (target - rs->q[action]);                       /* :43 */
   if (a->storage_f32) rs->q[action] = (double)(float)rs->q[action];        /* float32 table (option) */
@@ -487,6 +498,8 @@ int orc_agent_q(const orc_agent_t *a, const uint8_t *board, double out[4]) {
 
 int64_t orc_agent_size(const orc_agent_t *a) { return a->q->size; }
 void orc_agent_set_storage_f32(orc_agent_t *a, int on) { a->storage_f32 = on ? 1 : 0; }
+void orc_agent_set_frozen(orc_agent_t *a, int on) { a->frozen = on ? 1 : 0; }
+int64_t orc_agent_drops(const orc_agent_t *a) { return a->drops; }
 
 int64_t orc_agent_dump(const orc_agent_t *a, uint8_t *keys, double *vals, int64_t max_rows) {
   int64_t w = 0;
@@ -535,7 +548,7 @@ void orc_rollout_ex(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t step
       else if (actions) a = actions[t * B + i];
       else { a = orc_draw_action(x[1]); explored = 1; }                   /* random play */
       double r; int done, mx;
-      int64_t size0 = agent ? agent->q->size : 0;
+      int64_t size0 = agent ? agent->q->size : 0, drops0 = agent ? agent->drops : 0;
       int valid;
       if (env_flags & ORC_ENV_DQN) {
         uint32_t y[4];
@@ -555,6 +568,7 @@ void orc_rollout_ex(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t step
         stats_i[ORC_ST_VALID] += (valid > 0);
         stats_i[ORC_ST_EXPLORE] += explored;
         if (agent) stats_i[ORC_ST_INSERTS] += agent->q->size - size0;
+        if (agent) stats_i[ORC_ST_DROPS] += agent->drops - drops0;
       }
       if (stats_f) stats_f[ORC_SF_REWARD] += r;
       if (done) {
@@ -597,7 +611,7 @@ void orc_rollout_sync(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t st
       const int valid = orc_env_step(e, act[i], x[2], x[3], &r, &done, &mx);   /* :93 */
       uint8_t k2[ORC_MAXCELLS];
       orc_key_of(agent, e->board, k2);
-      const orc_row_t *rn = orc_qtable_get(agent->q, k2, NULL);                /* :41 */
+      const orc_row_t *rn = orc_row_of(agent, k2);                             /* :41 */
       const double qn = rn->q[orc_argmax4(rn->q, agent->action_space)];
       const double rf = (double)(float)r;  /* the device hands rewards over as float32 */
       target[i] = rf + (agent->gamma * qn * (double)(1 - (done ? 1 : 0)));     /* :42 */
@@ -625,6 +639,11 @@ void orc_rollout_sync(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t st
     for (int64_t i = 0; i < B; ++i) {                      /* phase 2: updates in env order */
       uint8_t k1[ORC_MAXCELLS];
       orc_key_of(agent, s_all + i * ORC_MAXCELLS, k1);
+      if (agent->frozen && !orc_qtable_find(agent->q, k1)) {                  /* closed key set: dropped */
+        agent->drops += 1;
+        if (stats_i) stats_i[ORC_ST_DROPS] += 1;
+        continue;
+      }
       orc_row_t *rs = orc_qtable_get(agent->q, k1, NULL);
       rs->q[act[i]] += agent->lr * (target[i] - rs->q[act[i]]);               /* :43 */
     }
@@ -633,7 +652,7 @@ void orc_rollout_sync(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t st
         uint8_t k1[ORC_MAXCELLS];
         orc_key_of(agent, s_all + i * ORC_MAXCELLS, k1);
         orc_row_t *rs = orc_qtable_find(agent->q, k1);
-        rs->q[act[i]] = (double)(float)rs->q[act[i]];
+        if (rs) rs->q[act[i]] = (double)(float)rs->q[act[i]];
       }
   }
   free(s_all); free(act); free(target);

@@ -1347,18 +1347,23 @@ def test_table_full_drops_are_counted_not_raised(pkg, O):
     assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16])
 
 
-@pytest.mark.parametrize("n", [4, 5])
-def test_rollout_on_a_full_table_stays_bounded(pkg, n):
-    """A FIXED table of 2^20 slots driven until it is full (with one probe limit of 2^14 for every
-    probe, each lookup of an absent key issued up to 16 384 dependent loads per lane, twice per step, and a launch
-    on a full table slowed by orders of magnitude before TABLE_FULL became visible).  The learning paths probe at
-    most 2^10 slots: launches on the full table stay within a small multiple of a launch on the young one, the
-    drops are counted, the status word says TABLE_FULL, and every row that was created is still found."""
+@pytest.mark.parametrize("n,freeze", [(4, 0.6), (5, 0.6), (4, None), (5, None)])
+def test_rollout_on_a_full_table_stays_bounded(pkg, n, freeze):
+    """A FIXED table of 2^22 slots under a run that wants far more rows than it has.
+    freeze_load = 0.6 (the default policy, SURVEY 7.3 "stop inserting and count drops"): the table closes its key set
+    within one launch of load 0.6; from then on the row count is constant, drops are counted, TABLE_FULL is NOT
+    raised, and a launch costs at most 3 x a launch on the young table (the ratio is printed; round 5 allowed 200 x
+    on a table driven to load 1.0).
+    freeze_load = None (the table is left to fill up): ADVICE r4's bound -- the learning paths probe at most 2^10
+    slots, so a launch on the FULL table stays within a (large) multiple of the young one, drops are counted, the
+    status word says TABLE_FULL, and every row that was created is still found."""
     import time
+    import warnings
 
-    B, S, cap = 1 << 16, 8, 20
+    B, S, cap = 1 << 16, 8, (22 if freeze is not None else 20)
     env = pkg.BatchedGame2048Env(B, board_size=n, seed=12, device=DEV)
-    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2=cap, seed=12, device=DEV, board_size=n)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2=cap, seed=12, device=DEV, board_size=n,
+                                      freeze_load=freeze)
 
     def launch():
         sync()
@@ -1369,19 +1374,178 @@ def test_rollout_on_a_full_table_stays_bounded(pkg, n):
 
     launch()
     young = min(launch() for _ in range(3))
-    for _ in range(40):                                   # ~0.6 rows per env-step: the table fills in a few launches
-        agent.fused_rollout(env, S)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for _ in range(40 if freeze is None else 60):     # ~0.6-0.9 rows per env-step
+            agent.fused_rollout(env, S)
     st = agent.stats()
     rows = agent.table_size()
-    assert rows > 0.9 * (1 << cap) and st["drops"] > 0 and rows == st["inserts"]
-    assert agent.check_status() & pkg._native.STATUS_TABLE_FULL
+    load = rows / (1 << cap)
     full = max(launch() for _ in range(3))
-    print(f"[full table {n}x{n}] load {rows / (1 << cap):.3f}: {full * 1e3:.2f} ms per {S}-step launch against "
-          f"{young * 1e3:.2f} ms on the young table")
-    assert full < max(200 * young, 0.5), (full, young)
+    print(f"[full table {n}x{n}, freeze_load {freeze}] load {load:.3f}: {full * 1e3:.2f} ms per {S}-step launch "
+          f"against {young * 1e3:.2f} ms on the young table = {full / young:.2f} x")
+    assert st["drops"] > 0 and rows == st["inserts"]
+    if freeze is None:
+        assert rows > 0.9 * (1 << cap) and not agent.frozen
+        assert agent.check_status() & pkg._native.STATUS_TABLE_FULL
+        assert full < max(200 * young, 0.5), (full, young)
+    else:
+        assert agent.frozen and agent.frozen_at["rows"] == rows                     # nothing was created since
+        assert freeze <= load <= freeze + 2.0 * B * S / (1 << cap), load           # within one launch of the limit
+        assert agent.check_status() == 0                                            # the caller's policy: no TABLE_FULL
+        assert sum("takes no new rows" in str(w.message) for w in caught) == 1      # said once
+        assert agent.table_size() == rows and agent.stats()["inserts"] == rows     # the three launches above: none
+        assert full < 3.0 * young, (full, young)
+        assert agent.verify_table()["rows"] == rows
     k, q = agent.export_rows()                            # every created row is in the table, once
     assert len(q) == rows and len(np.unique(k.reshape(len(q), -1), axis=0)) == rows
     assert pkg._native.claim_timeouts(LIB(pkg)) == 0
+
+
+@pytest.mark.parametrize("n,path", [(4, "fused"), (5, "fused"), (4, "four_call"), (5, "four_call"), (4, "strict")])
+def test_closed_key_set_private_rows_match_oracle(pkg, O, n, path):
+    """Q2048_FLAG_NO_NEW_ROWS with private rows (every env = one reference agent whose dict stops taking keys after
+    k1 steps: the oracle's `freeze()`): epsilon = 0.3, so the actions depend on the rows AND on absent states reading
+    as the zero row the defaultdict would have created (Agent/main.py:16,38,41).  Boards and aux bit-exact, every row
+    of the closed key set within 1e-5, the key set itself unchanged, drops == the oracle's count of updates whose
+    state has no row, no TABLE_FULL.  Through the fused kernel (also with compare-and-swap TD writes) and the
+    4-call API."""
+    B, k1, k2, seed, id0, eps, lr, gamma = 96, 50, 250, 23, 7000, 0.3, 0.1, 0.99
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                      capacity_log2=17, seed=seed, env_id0=id0, device=DEV, independent=True,
+                                      board_size=n, freeze_load=None, strict_td=path == "strict")
+
+    def run(k):
+        if path == "four_call":
+            _unfused_loop(pkg, env, agent, k)
+        else:
+            agent.fused_rollout(env, k // 3)              # (split launches: the flag travels with each)
+            agent.fused_rollout(env, k - k // 3)
+
+    run(k1)
+    rows1 = agent.table_size()
+    agent.frozen = True                                   # the key set is closed by hand (the policy has its own test)
+    run(k2)
+    envs = O.envs_init(B, n, seed, id0)
+    drops, rows, worst = 0, 0, 0.0
+    for i in range(B):
+        oa = O.Agent(100, 4, lr, gamma, eps, n=n)
+        O.rollout(envs[i:i + 1], oa, k1, seed, id0 + i, 0)
+        size1 = len(oa)
+        oa.freeze()
+        si, _ = O.rollout(envs[i:i + 1], oa, k2, seed, id0 + i, k1)
+        assert len(oa) == size1 and si[O.ST_DROPS] == oa.drops
+        drops += oa.drops
+        rows += size1
+        keys, vals = oa.dump()
+        got, found = agent.q_values(t8(keys), env_id=id0 + i, return_found=True)
+        assert bool(found.all()), i
+        got = got.cpu().numpy()
+        assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), i
+        worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :n * n])
+    assert_aux(env.aux_fields(), envs, "closed key set")
+    st = agent.stats()
+    print(f"[closed key set {n}x{n} {path}] {rows} rows, {drops} of {B * k2} updates dropped, worst relative Q error {worst:.2e}")
+    assert drops > 0.2 * B * k2                           # most of a 2048 game's states are new
+    assert st["drops"] == drops and st["inserts"] == rows == rows1 == agent.table_size()
+    assert (path == "four_call" or st["steps"] == B * (k1 + k2)) and agent.check_status() == 0
+    assert pkg._native.claim_timeouts(LIB(pkg)) == 0
+
+
+@pytest.mark.parametrize("n", [4, 5])
+def test_closed_key_set_shared_table_drops_match_oracle(pkg, O, n):
+    """One SHARED table, 20 000 envs, epsilon = 1 (the trajectories are the draws'): 40 steps of ordinary learning, then
+    the key set is closed for 80 more.  The table's key set afterwards IS the oracle dict's at the moment it froze,
+    and the number of dropped updates equals the oracle's count of env-steps taken from a state outside that set --
+    a function of the draws alone, whatever the order in which the lanes ran."""
+    B, k1, k2, seed, id0 = 20000, 40, 80, 6, 99
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, discount_factor=0.0, capacity_log2=22, seed=seed,
+                                      env_id0=id0, device=DEV, board_size=n, freeze_load=None)
+    agent.fused_rollout(env, k1)
+    agent.frozen = True
+    agent.fused_rollout(env, k2)
+    envs = O.envs_init(B, n, seed, id0)
+    oa = O.Agent(100, 4, 0.1, 0.0, 1.0, n=n)
+    O.rollout(envs, oa, k1, seed, id0, 0)
+    size1 = len(oa)
+    oa.freeze()
+    si, _ = O.rollout(envs, oa, k2, seed, id0, k1)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :n * n])
+    assert_aux(env.aux_fields(), envs, "closed key set, shared")
+    st = agent.stats()
+    assert len(oa) == size1 == st["inserts"] == agent.table_size()
+    assert st["drops"] == si[O.ST_DROPS] == oa.drops > 0.5 * B * k2
+    keys, _ = oa.dump()
+    _, found = agent.q_values(t8(keys), return_found=True)
+    assert bool(found.all()) and agent.check_status() == 0
+    print(f"[closed key set {n}x{n}, shared] {size1} rows, {st['drops']} of {B * k2} updates dropped == the oracle's count")
+
+
+@pytest.mark.parametrize("n", [4, 5])
+def test_closed_key_set_deterministic_mode_is_bit_exact(pkg, O, n):
+    """The deterministic step with Q2048_FLAG_NO_NEW_ROWS on a SHARED table at epsilon 0.2 against the oracle's
+    two-phase semantic with a dict that stopped taking keys (float32 rows): boards bit-exact, the WHOLE table
+    bit-exact, the same drops."""
+    B, k1, k2, seed, id0, eps, lr, gamma = 3000, 30, 90, 41, 10, 0.2, 0.1, 0.95
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                      capacity_log2=20, seed=seed, env_id0=id0, device=DEV, board_size=n,
+                                      freeze_load=None)
+    agent.deterministic_rollout(env, k1)
+    agent.frozen = True
+    agent.deterministic_rollout(env, k2 // 2)
+    agent.deterministic_rollout(env, k2 - k2 // 2)
+    envs = O.envs_init(B, n, seed, id0)
+    oa = O.Agent(100, 4, lr, gamma, eps, n=n, storage_f32=True)
+    si1, _ = O.rollout_sync(envs, oa, k1, seed, id0, 0)
+    size1 = len(oa)
+    oa.freeze()
+    si, _ = O.rollout_sync(envs, oa, k2, seed, id0, k1)
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :n * n])
+    assert_aux(env.aux_fields(), envs, "closed key set, deterministic")
+    keys, vals = oa.dump()
+    got = agent.q_values(t8(keys)).cpu().numpy()
+    assert np.array_equal(got, vals.astype(np.float32)), f"{(got != vals.astype(np.float32)).sum()} entries differ"
+    st = agent.stats()
+    assert len(oa) == size1 == st["inserts"] == agent.table_size()
+    assert st["drops"] == si[O.ST_DROPS] == oa.drops > 0 and st["explored"] == si1[O.ST_EXPLORE] + si[O.ST_EXPLORE]
+    assert agent.check_status() == 0
+
+
+def test_growing_table_freezes_at_its_largest_capacity(pkg):
+    """capacity_log2="auto" with max_capacity_log2 = 2^20: the table grows 2^16 -> 2^18 -> 2^20 like the defaultdict
+    (every growth checks rows moved == rows created), then -- it cannot grow any more -- closes its key set at
+    freeze_load; the run goes on at the young table's speed class, `verify_table` still holds, a checkpoint of the
+    frozen learner loads into a fresh agent that freezes again at its first launch."""
+    import warnings
+
+    B, S, seed = 8192, 8, 3
+    env = pkg.BatchedGame2048Env(B, seed=seed, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=0.9, capacity_log2="auto", initial_capacity_log2=16,
+                                      max_capacity_log2=20, seed=seed, device=DEV, freeze_load=0.5)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for _ in range(40):
+            agent.fused_rollout(env, S)
+    agent.finish_growth()
+    assert agent.capacity_log2 == 20 and [g["to_log2"] for g in agent.growths][-1] == 20
+    assert agent.frozen and sum("takes no new rows" in str(w.message) for w in caught) == 1
+    check = agent.verify_table()
+    assert 0.5 <= check["load"] <= 0.5 + 2.0 * B * S / (1 << 20) and check["rows"] == agent.frozen_at["rows"]
+    st = agent.stats()
+    assert st["drops"] > 0 and st["inserts"] == check["rows"] and agent.check_status() == 0
+    sd = agent.state_dict()
+    fresh = pkg.BatchedQLearningAgent(100, exploration_rate=0.9, capacity_log2=20, seed=seed, device=DEV, freeze_load=0.5)
+    fresh.load_state_dict(sd)
+    assert not fresh.frozen
+    env.ctr = fresh.ctr
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fresh.fused_rollout(env, S)
+    assert fresh.frozen and fresh.table_size() == check["rows"]
 
 
 @pytest.mark.parametrize("n", [4, 5])

@@ -39,6 +39,8 @@ ON_CPU = [
     "test_legal_moves_mask", "test_encode_onehot_matches_reference_encoder", "test_tile_overflow_is_reported",
     "test_steps_counter_and_argument_checks", "test_deterministic_mode_batch_edges",
     "test_no_learn_rollout_reads_but_never_writes", "test_rollout_on_a_full_table_stays_bounded",
+    "test_closed_key_set_private_rows_match_oracle", "test_closed_key_set_shared_table_drops_match_oracle",
+    "test_closed_key_set_deterministic_mode_is_bit_exact", "test_growing_table_freezes_at_its_largest_capacity",
 ]
 for _name in ON_CPU:
     globals()[_name.replace("_on_device", "") + "_on_cpu"] = getattr(_par, _name)

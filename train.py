@@ -58,6 +58,13 @@ def parse_args(argv=None):
     p.add_argument("--initial-capacity-log2", type=int, default=0,
                    help="first capacity of the growing table; 0 (default) = 2^30 slots (32 GiB) when that is at most "
                         "an eighth of the free device memory, else the largest power of two that is")
+    p.add_argument("--freeze-load", type=float, default=0.6,
+                   help="what a table does when it cannot grow any more (--capacity-log2, or the growing table at the "
+                        "largest capacity the device holds): once this share of its slots holds rows it takes no new "
+                        "rows -- rows that exist keep learning, a state without a row reads as zeros (the defaultdict's "
+                        "fresh row, Agent/main.py:16) and its updates are dropped and counted in the Drops column "
+                        "(SURVEY 7.3; Q2048_FLAG_NO_NEW_ROWS).  0 = never: the table fills up and slows down by orders "
+                        "of magnitude")
     p.add_argument("--growth", choices=["async", "sync"], default="async",
                    help="async (default): growth off the critical path (q2048_table_grow_begin / _commit / _finish); "
                         "sync: the host-synchronous q2048_table_grow (same table, bit for bit)")
@@ -188,7 +195,7 @@ def train_batched(args, pkg):
                                           args.epsilon_min, cap, dev, args.seed, shard.env_id0,
                                           strict_td=args.strict_td, board_size=args.board_size,
                                           initial_capacity_log2=args.initial_capacity_log2 or "auto",
-                                          async_growth=args.growth == "async")
+                                          async_growth=args.growth == "async", freeze_load=args.freeze_load or None)
     if args.deterministic and args.agent != "hash":
         raise SystemExit("--deterministic applies to the hash-table agent")
     if (args.save or args.resume) and args.agent != "hash":
@@ -232,7 +239,7 @@ def train_batched(args, pkg):
         total_eps = pkg.stats_dict(*reducer.wait())["episodes"]
     stop_epoch = min(args.episodes, args.stop_epoch) if args.stop_epoch else args.episodes
     target = stop_epoch * shard.total_envs
-    best_tile, grown, reports = 0, 0, 0
+    best_tile, grown, reports, said_frozen = 0, 0, 0, False
     agent.train_progress = {"epoch": epoch}
     agent.train_env = env
     while total_eps < target:
@@ -265,6 +272,11 @@ def train_batched(args, pkg):
             if args.verify_every and reports % args.verify_every == 0:
                 agent.verify_table()
             grown = _report_growths(agent, grown, rank)
+            if agent.frozen and not said_frozen:
+                said_frozen, f = True, agent.frozen_at
+                print(f"[rank {rank}] table frozen at step {f['at_step']}: 2^{f['capacity_log2']} slots hold {f['rows']} "
+                      f"rows (load {f['load']:.3f} >= --freeze-load {agent.freeze_load}); no new rows from here on, "
+                      "updates of states without a row are dropped and counted", flush=True)
         if rank == 0:
             rate = st["steps"] / (time.time() - t0)
             with open(args.log, mode="a", newline="") as fh:
@@ -281,7 +293,7 @@ def train_batched(args, pkg):
         check = agent.verify_table()                      # (waits for a growth still in flight and checks it too)
         grown = _report_growths(agent, grown, rank)
         print(f"[rank {rank}] table check passed: {check['rows']} rows == rows created, 2^{check['capacity_log2']} "
-              f"slots, load {check['load']:.3f}", flush=True)
+              f"slots, load {check['load']:.3f}" + (" (frozen)" if agent.frozen else ""), flush=True)
     return agent
 
 
