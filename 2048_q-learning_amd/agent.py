@@ -342,10 +342,12 @@ class BatchedQLearningAgent:
                     within one launch of the limit), every launch carries Q2048_FLAG_NO_NEW_ROWS: rows that exist keep
                     learning, a state without a row reads as the zero row the defaultdict would have created, is not
                     created, and its update is dropped and counted (stats['drops']); a warning says so once and
-                    `frozen` is True from then on.  Default 0.6: at 1 Mi boards the step on a table frozen there costs
-                    what the growing table's costs at its load limit, where a table driven to load 1.0 takes 12.9 ms
-                    per step (profiles/r05_claim_first_ab.jsonl).  None: never freeze -- the table fills up, probes of
-                    absent states walk up to 2^10 slots, and updates that find no slot are dropped (status TABLE_FULL).
+                    `frozen` is True from then on.  Default 0.5: a 1 Mi-board step on a table frozen there costs what
+                    the young learning table's costs (4x4: 47.3 us against 45.5; 5x5: 61.4 against 61.5), at 0.6 it is
+                    65.9 / 85.5 us, at 0.7 101 / 140, at 0.9 823 / 1206 (profiles/r06_load_curve_frozen*.jsonl), and a
+                    table driven to load 1.0 takes 12.9 ms (profiles/r05_claim_first_ab.jsonl).  None: never freeze --
+                    the table fills up, probes of absent states walk up to 2^10 slots, and updates that find no slot
+                    are dropped (status TABLE_FULL).
     independent     every env owns private rows (keys salted with its global id): B independent
                     learners in one table, exactly B reference agents side by side.
     placement       how the table is allocated (`place_table`): "auto", "chunks", "plain" or a count
@@ -364,7 +366,7 @@ class BatchedQLearningAgent:
                  strict_td: bool = False, board_size: int = 4, placement="auto", row_cache: bool = True,
                  initial_capacity_log2="auto", max_capacity_log2: int | None = None, load_limit: float = 0.35,
                  growth_step_log2: int = 2, prefetch_growth: bool = True, async_growth: bool = True,
-                 verify_growth: bool = False, freeze_load: "float | None" = 0.6):
+                 verify_growth: bool = False, freeze_load: "float | None" = 0.5):
         self.device = _require_gpu(device)
         self._L = N.lib_for(self.device)
         self.on_gpu = self.device.type == "cuda"

@@ -41,9 +41,10 @@ Extra objects on the line:
                 every N): all cores and one thread, with the CPU model; and, under `product_core`, the
                 product's own CPU twin (libq2048_host.so, device "cpu"; kind "product-core") on the same
                 cores: the kernels' per-lane arithmetic and table, one shared table as on the GPU.
-  companions    the same protocol at SURVEY 8(d)'s 2^28-slot table, at eps = 0.01, on 5x5 boards and on a table
-                pre-filled (untimed) to load 0.45 -- the steady state of a long run; the main line's table is
-                young (N = 1 only).
+  companions    the same protocol at SURVEY 8(d)'s 2^28-slot table, at eps = 0.01, on 5x5 boards and on a FROZEN
+                table -- pre-filled (untimed) to freeze_load 0.5, key set closed (Q2048_FLAG_NO_NEW_ROWS): where a
+                run lives once its table has reached the largest capacity the device holds, i.e. after the first
+                ~4e9 env-steps per GPU; the main line's table is young (N = 1 only).
 
 `--check-shards` is a different job (no timing): every rank plays K steps of its shard at eps = 1
 and rank 0 prints 64-bit hashes of boards + aux per 4096 global env ids -- equal lists for N = 1
@@ -74,7 +75,7 @@ ALGO_BYTES_FUSED_5X5 = 156
 ALGO_BYTES_ROW_TUPLE = 64 + 8 * 16 + 4 * 4 + 6
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
-STEADY_LOAD = 0.45          # the pre-filled companion's table load (a growing table's limit is 0.5)
+FREEZE_LOAD = 0.5           # the frozen companion: BatchedQLearningAgent's default freeze_load
 PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r05_pmc_traffic.json", "r05_pmc_traffic_k20.json")]
 CSRC = os.path.join(REPO, "2048_q-learning_amd", "csrc")
 KERNEL_SOURCES = ("q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc")
@@ -130,6 +131,9 @@ def parse_args(argv=None):
     p.add_argument("--check-shards", action="store_true",
                    help="no timing: play --steps steps at eps = 1 and print per-chunk hashes of boards + aux "
                         "(compare N = 1 with N = 2 over the same global env ids)")
+    p.add_argument("--device", default="cuda",
+                   help='--check-shards only: "cpu" plays the shards on the CPU twin (libq2048_host.so) over gloo -- the '
+                        "N-rank partition rehearsed without GPUs (the timed bench is the MI355X path and takes no device)")
     p.add_argument("--launch-timeout", type=float, default=3000.0,
                    help="self-launched ranks (--gpus N > 1 outside torchrun) are stopped after this many seconds")
     return p.parse_args(argv)
@@ -285,7 +289,7 @@ def cpu_baseline_product_core(pkg, torch, args, seconds: float) -> dict:
 
 
 def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, steps, warmup, repeats,
-            S, reducer, board_size=None, prefill_load=0.0):
+            S, reducer, board_size=None, prefill_load=0.0, expect_frozen=False):
     """The protocol of the module docstring for one configuration.  Returns a dict of raw
     measurements (region times are MAX over ranks)."""
     board_size = args.board_size if board_size is None else board_size
@@ -377,12 +381,15 @@ def measure(pkg, torch, args, dev, shard, world, *, eps, cap_log2, placement, st
         r["wall_s"], r["kernel_ms"] = worst[k], worst[len(regions) + k]
     table_rows = agent.table_size() if args.agent == "hash" else None
     status = agent.check_status()
+    frozen = bool(getattr(agent, "frozen", False))
+    if expect_frozen and (not frozen or table_rows != prefilled_rows):
+        raise SystemExit(f"the frozen companion's table was not frozen ({frozen}) or took rows ({table_rows} != {prefilled_rows})")
     placement_report = getattr(agent, "placement", None)
     del agent, synth, env
     torch.cuda.empty_cache()
     return {"regions": regions, "table_rows": table_rows, "status": status, "mirrored": mirrored,
             "placement": placement_report, "prep_episodes_per_env": prep_episodes_per_env,
-            "prefilled_rows": prefilled_rows}
+            "prefilled_rows": prefilled_rows, "frozen": frozen}
 
 
 def summarise(m, shard, steps, algo_bytes):
@@ -534,13 +541,15 @@ def run_rank(args):
                 ("epsilon 0.01 (argmax path)", 0.01, cap_log2, args.board_size, 0.0),
                 ("5x5 boards (BASELINE configs[4])", args.eps, cap5, 5, 0.0),
                 # the main line runs on a YOUNG table (load < 0.1 at the driver's K = 20): this is the same workload
-                # on the table of a run that has been going on for a while -- pre-filled (untimed) to load
-                # STEADY_LOAD, where a growing table spends the end of every growth cycle
-                (f"steady state: table pre-filled to load {STEADY_LOAD}", args.eps, cap_log2, args.board_size, STEADY_LOAD)):
+                # on the table of a LONG run -- one that has reached its largest capacity and closed its key set at
+                # freeze_load (pre-filled, untimed, to just above it: the agent's own policy freezes it at its first
+                # launch): existing rows learn, absent states read as zeros, their updates are dropped and counted
+                (f"frozen table: pre-filled to load {FREEZE_LOAD}, key set closed (Q2048_FLAG_NO_NEW_ROWS)", args.eps,
+                 cap_log2, args.board_size, FREEZE_LOAD + 0.002)):
             if c_n == args.board_size and name.startswith("5x5"):
                 continue
-            # learning steps the table can take: up to load 0.5; a pre-filled one at most 0.05 beyond its fill
-            budget = int((0.05 if c_fill else 0.5) * (1 << c_cap) / (0.75 * B))
+            # learning steps the table can take: up to load 0.5 (the frozen one takes no rows: no limit)
+            budget = int(0.5 * (1 << c_cap) / (0.75 * B)) if not c_fill else args.warmup + 4 * args.steps
             c_rep = 3
             c_steps = max(1, min(args.steps, budget // (c_rep + 1)))
             c_warm = max(1, min(args.warmup, budget - c_rep * c_steps))
@@ -548,7 +557,7 @@ def run_rank(args):
             c_bytes = ALGO_BYTES_FUSED_4X4 if c_n == 4 else ALGO_BYTES_FUSED_5X5
             cm = measure(pkg, torch, args, dev, shard, world, eps=c_eps, cap_log2=c_cap,
                          placement=args.placement, steps=c_steps, warmup=c_warm, repeats=c_rep, S=c_S,
-                         reducer=reducer, board_size=c_n, prefill_load=c_fill)
+                         reducer=reducer, board_size=c_n, prefill_load=c_fill, expect_frozen=bool(c_fill))
             cs = summarise(cm, shard, c_steps, c_bytes)
             cst = cs["median_region"]["stats"]
             comps.append({"name": name, "epsilon": c_eps, "table_capacity_log2": c_cap, "board_size": c_n,
@@ -559,7 +568,8 @@ def run_rank(args):
                           "roofline_frac": cs["achieved_gbs"] / HBM_PEAK_GBS,
                           "inserts_per_step": cst["inserts"] / max(cst["steps"], 1),
                           "episodes": cst["episodes"], "table_placement": cm["placement"],
-                          "prefilled_rows": cm["prefilled_rows"],
+                          "prefilled_rows": cm["prefilled_rows"], "frozen": cm["frozen"],
+                          "drops_per_step": cst["drops"] / max(cst["steps"], 1),
                           "table_load_factor": cm["table_rows"] / float(1 << c_cap)})
         out["companions"] = comps
 
@@ -592,13 +602,17 @@ def check_shards(args):
     import torch
 
     pkg = importlib.import_module("2048_q-learning_amd")
-    rank, local_rank, world = pkg.dist.init_process_group()
+    on_cpu = args.device == "cpu"
+    rank, local_rank, world = pkg.dist.init_process_group("gloo" if on_cpu else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
-    torch.cuda.set_device(dev)
+    if on_cpu:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+        dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+        torch.cuda.set_device(dev)
     shard = pkg.weak_shard(args.boards_per_gpu, world, rank)
     if shard.num_envs % SHARD_CHUNK:
         raise SystemExit(f"--boards-per-gpu must be a multiple of {SHARD_CHUNK}")
@@ -659,6 +673,8 @@ def main(argv=None):
                                                line_filter=lambda ln: ln.lstrip().startswith("{")))
     if args.check_shards:
         check_shards(args)
+    elif args.device != "cuda":
+        raise SystemExit("--device applies to --check-shards; the timed bench is the MI355X path")
     else:
         run_rank(args)
 

@@ -126,7 +126,7 @@ extern "C" {
                                          Q2048_ST_DROPS; Q2048_STATUS_TABLE_FULL is NOT raised (the caller asked).
                                      q2048_q_update / _cached, q2048_fused_rollout*, q2048_det_rollout; ignored by the
                                      entry points that never create rows (choose, lookup, env, NO_LEARN, PLAY_ONLY).
-                                     The host decides when: BatchedQLearningAgent(freeze_load=0.6) sets it on every
+                                     The host decides when: BatchedQLearningAgent(freeze_load=0.5) sets it on every
                                      launch once a table at its largest capacity holds that share of rows */
 
 /* per-env state, Game2048_env.__init__ (Game2048_env.py:81-95) + episode bookkeeping */

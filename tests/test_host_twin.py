@@ -149,6 +149,55 @@ def test_train_two_ranks_on_the_cpu_device_equal_one_rank(tmp_path):
         assert int(a[8]) == int(b[8]) == 0                       # no drops
 
 
+def test_eight_ranks_on_the_cpu_device_equal_one_rank(tmp_path):
+    """BASELINE configs[3]'s partition at its real world size, without GPUs: EIGHT self-launched ranks (launch.py: eight
+    fresh children, a gloo group) on the CPU twin, each owning the global env ids [r B, (r + 1) B) and its own table
+    replica.
+      1. `bench.py --check-shards --device cpu --gpus 8`: the per-chunk hashes of boards + aux over the global ids
+         [0, 8 B) equal those of ONE rank playing all 8 B ids -- rank 7's ids start at 7 B, and a trajectory does not
+         depend on the sharding.
+      2. `train.py --gpus 8 --device cpu` on GROWING replicas: every rank's table grows on its own (each growth
+         checked: rows moved == rows created) and passes its end-of-run check, and the job's rows -- episodes,
+         env-steps, score, best tile: the 8-way statistics reduction, summed in rank order -- equal the 1-rank run's.
+    No scaling curve comes out of this (eight processes share this host's cores): it is the correctness of the
+    8-way split, the launcher and the reduction."""
+    import csv
+    import json
+    import subprocess
+
+    env = dict(os.environ, Q2048_HOST_THREADS="1")
+    def shards(gpus, per):
+        p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--check-shards", "--device", "cpu", "--gpus",
+                            str(gpus), "--boards-per-gpu", str(per), "--steps", "24", "--steps-per-launch", "8"],
+                           capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+    eight, one = shards(8, 4096), shards(1, 32768)
+    assert eight["n_gpus"] == 8 and eight["total_envs"] == one["total_envs"] == 32768
+    assert eight["hashes"] == one["hashes"] and len(one["hashes"]) == 8 and len(set(one["hashes"])) == 8
+    assert eight["episodes"] == one["episodes"] and eight["env_steps"] == one["env_steps"] == 32768 * 24
+    assert eight["status"] == one["status"] == 0
+
+    common = ["--device", "cpu", "--epsilon", "1.0", "--max-steps", "64", "--steps-per-launch", "32", "--episodes", "50",
+              "--initial-capacity-log2", "12"]
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(REPO, "train.py"), *common, *a],   # noqa: E731
+                                    capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    p8 = run("--gpus", "8", "--num-envs", "1024", "--log", "eight.csv")
+    assert p8.returncode == 0, p8.stderr[-2000:]
+    out8 = p8.stdout + p8.stderr
+    assert out8.count("table check passed") == 8                 # every rank checked its replica
+    assert all(f"[rank {r}] table grew" in out8 for r in range(8))   # ... which grew on its own
+    p1 = run("--num-envs", "8192", "--log", "one.csv")
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    rows8, rows1 = (list(csv.reader(open(tmp_path / f)))[1:] for f in ("eight.csv", "one.csv"))
+    assert len(rows8) == len(rows1) == 2 and int(rows8[-1][2]) == 8192 * 64
+    for a, b in zip(rows8, rows1):
+        assert a[:4] == b[:4] and a[5:7] == b[5:7]               # epoch, episodes, env-steps, epsilon; score, best tile
+        assert abs(float(a[4]) - float(b[4])) <= 1e-3 * abs(float(b[4]))   # mean return: a float sum in another order
+        assert int(a[8]) == int(b[8]) == 0                       # no drops
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_fuzz_parity_on_the_cpu_device(seed):
     """tests/fuzz_parity.py (the confidence run of the GPU parity check: random geometry, batch, steps, epsilon,

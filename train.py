@@ -58,7 +58,7 @@ def parse_args(argv=None):
     p.add_argument("--initial-capacity-log2", type=int, default=0,
                    help="first capacity of the growing table; 0 (default) = 2^30 slots (32 GiB) when that is at most "
                         "an eighth of the free device memory, else the largest power of two that is")
-    p.add_argument("--freeze-load", type=float, default=0.6,
+    p.add_argument("--freeze-load", type=float, default=0.5,
                    help="what a table does when it cannot grow any more (--capacity-log2, or the growing table at the "
                         "largest capacity the device holds): once this share of its slots holds rows it takes no new "
                         "rows -- rows that exist keep learning, a state without a row reads as zeros (the defaultdict's "
