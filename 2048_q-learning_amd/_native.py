@@ -28,7 +28,7 @@ DEPS = ["q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.in
 
 OK, PENDING, ERR_ALLOC, ERR_BUSY = 0, 1, -8, -10
 GROW_VERIFY_COUNT = 1
-STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL = 1, 2, 4
+STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL, STATUS_DEEP_ROW = 1, 2, 4, 8
 FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
 FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY, FLAG_NO_LEARN, FLAG_NO_NEW_ROWS = 8, 16, 32, 64, 128
 ABI_VERSION = 6

@@ -341,8 +341,10 @@ class BatchedQLearningAgent:
                     capacity in rows (checked between launches with the kernels' own insert counter, so the load ends
                     within one launch of the limit), every launch carries Q2048_FLAG_NO_NEW_ROWS: rows that exist keep
                     learning, a state without a row reads as the zero row the defaultdict would have created, is not
-                    created, and its update is dropped and counted (stats['drops']); a warning says so once and
-                    `frozen` is True from then on.  Default 0.5: a 1 Mi-board step on a table frozen there costs what
+                    created, and its update is dropped and counted (stats['drops']) -- landing in the env's VISIT ROW,
+                    which stands in for the missing row while the env stays in that state (so that an invalid move
+                    teaches the next greedy choice, as the defaultdict's fresh row would) and ends when it moves on;
+                    a warning says so once and `frozen` is True from then on.  Default 0.5: a 1 Mi-board step on a table frozen there costs what
                     the young learning table's costs (4x4: 47.3 us against 45.5; 5x5: 61.4 against 61.5), at 0.6 it is
                     65.9 / 85.5 us, at 0.7 101 / 140, at 0.9 823 / 1206 (profiles/r06_load_curve_frozen*.jsonl), and a
                     table driven to load 1.0 takes 12.9 ms (profiles/r05_claim_first_ab.jsonl).  None: never freeze --
@@ -398,8 +400,10 @@ class BatchedQLearningAgent:
             if initial_capacity_log2 == "auto":   # an eighth of the free memory, at most 2^30 slots (32 GiB)
                 initial_capacity_log2 = min(30, max(20, int(np.floor(np.log2(max(share / 8 / N.SIZEOF_SLOT, 2.0))))))
             capacity_log2 = int(initial_capacity_log2)
-            # the largest table that fits next to its predecessor while the rows move over
-            fit = int(np.floor(np.log2(max(0.9 * share / (1.5 * N.SIZEOF_SLOT), 16.0))))
+            # the largest table that fits next to its predecessor while the rows move over -- and next to the retired
+            # tables of earlier growths, which are kept until their memory is needed: with fourfold steps everything
+            # below the largest table adds up to a third of it, the uneven last step to a little more (1.7 in all)
+            fit = int(np.floor(np.log2(max(0.9 * share / (1.7 * N.SIZEOF_SLOT), 16.0))))
             self.max_capacity_log2 = max(capacity_log2, min(int(max_capacity_log2 or 34), fit, 40))
             placement = "chunks" if self.on_gpu else "plain"   # on a GPU growth is a property of the chunk allocator
         else:
@@ -493,7 +497,7 @@ class BatchedQLearningAgent:
         actions = torch.empty(B, dtype=torch.uint8, device=self.device)
         N.check(self._L.q2048_q_choose_cached(
             _ptr(self.table), self.capacity_log2, _ptr(boards), B, self.board_size, float(self.epsilon),
-            self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self.flags, _ptr(self._cache(B)), _ptr(actions),
+            self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self._learn_flags(), _ptr(self._cache(B)), _ptr(actions),
             _ptr(self.status), _stream(self.device)), "q_choose")
         self.ctr += 1
         return actions
@@ -1006,8 +1010,12 @@ class BatchedQLearningAgent:
         N.check(self._L.q2048_table_import(_ptr(self.table), self.capacity_log2, _ptr(tk), _ptr(tq),  # agent's
                                            rows, keys.shape[1], _ptr(status),                          # is sticky
                                            _stream(self.device)), "table_import")
-        if int(status.item()) & N.STATUS_TABLE_FULL:
+        code = int(status.item())
+        if code & N.STATUS_TABLE_FULL:
             raise RuntimeError("table_import dropped rows (probe limit)")
+        if code & N.STATUS_DEEP_ROW:
+            warnings.warn("table_import placed rows deeper than the learning paths probe (2^10 slots): q_values finds "
+                          "them, choose / update / rollouts read them as absent -- load the checkpoint into a larger table")
         self._rebase_rows(self.table_size())
 
     def import_rows_device(self, keys: torch.Tensor, q: torch.Tensor) -> None:
@@ -1275,9 +1283,10 @@ class QLearningAgent:
         io, b = self._io, self._b
         off = io.take(32)                                        # [0:16] state in, [16] action out
         state_to_log2(state, io.np[off:off + 16])
-        N.check(b._L.q2048_q_choose(
+        N.check(b._L.q2048_q_choose_cached(
             _ptr(b.table), b.capacity_log2, io.ptr + off, 1, 4, float(b.epsilon), b.seed, b.env_id0,
-            b.ctr & 0xFFFFFFFF, b.flags, io.ptr + off + 16, _ptr(b.status), _stream(b.device)), "q_choose")
+            b.ctr & 0xFFFFFFFF, b._learn_flags(), _ptr(b._cache(1)), io.ptr + off + 16, _ptr(b.status),
+            _stream(b.device)), "q_choose")
         b.ctr += 1
         io.sync()
         return int(io.np[off + 16])
@@ -1292,10 +1301,11 @@ class QLearningAgent:
         state_to_log2(next_state, buf[off + 16:off + 32])
         buf[off + 32], buf[off + 33] = int(action), 1 if done else 0
         buf[off + 36:off + 40].view(np.float32)[0] = reward
-        N.check(b._L.q2048_q_update(
+        b._room_for(1)                # (the table's policy -- growth, or the closed key set of one that cannot grow)
+        N.check(b._L.q2048_q_update_cached(
             _ptr(b.table), b.capacity_log2, io.ptr + off, io.ptr + off + 32, io.ptr + off + 36,
-            io.ptr + off + 16, io.ptr + off + 33, 1, 4, float(b.lr), float(b.gamma), b.env_id0, b.flags,
-            _ptr(b.stats_i), _ptr(b.status), _stream(b.device)), "q_update")
+            io.ptr + off + 16, io.ptr + off + 33, 1, 4, float(b.lr), float(b.gamma), b.env_id0, b._learn_flags(),
+            _ptr(b._cache(1)), _ptr(b.stats_i), _ptr(b.status), _stream(b.device)), "q_update")
 
     def decay_exploration(self, current_epoch) -> None:
         self._b.decay_exploration(current_epoch)

@@ -805,39 +805,56 @@ __device__ __forceinline__ u64 cache_tag(const q2048_slot* table, u64 mask) {
   return (mix64((u64)reinterpret_cast<uintptr_t>(table) ^ (mask * 0x9E3779B97F4A7C15ull)) >> 40) << 40;
 }
 constexpr u64 kCacheSlotMask = (1ull << 40) - 1ull;
+// VISIT ROWS (Q2048_FLAG_NO_NEW_ROWS).  With the key set closed a state without a row reads as the zero row the
+// defaultdict would have created -- and while the env STAYS in that state (invalid moves) that fresh row learns as the
+// defaultdict's would (Agent/main.py:43): the lane keeps it in the registers that otherwise carry the table's row, so
+// that the first invalid move's negative reward sends argmax on to the next action instead of repeating action 0 until
+// the stall rule ends the episode.  It is never part of the table and ends when the env leaves the state.  Across a
+// launch boundary it travels like any carried row, through the row cache, as a ROWLESS record: slot field all ones
+// (no table of 2^40 slots exists).  Only calls that carry the flag write or accept such records.
+constexpr u64 kCacheRowless = kCacheSlotMask;
+__device__ __forceinline__ bool cache_slot(u64 s, bool rowless_ok, int64_t& slot) {
+  const u64 v = s & kCacheSlotMask;
+  if (v == kCacheRowless) { slot = INT64_MIN; return rowless_ok; }   // (INT64_MIN = kNoSlot, defined below)
+  slot = (int64_t)v;
+  return true;
+}
 __device__ __forceinline__ bool cache_get(const RowCache<4>* c, int64_t i, const Geo<4>::Key& key, u64 tag, Row& r,
-                                          int64_t& slot) {
+                                          int64_t& slot, bool rowless_ok = false) {
   const uint4* p = reinterpret_cast<const uint4*>(c + i);
   const uint4 a = p[0], b = p[1];
   const u64 s = (u64)b.z | ((u64)b.w << 32);
-  if (((u64)a.x | ((u64)a.y << 32)) != key.k0 || (s & ~kCacheSlotMask) != tag) return false;
+  int64_t at;
+  if (((u64)a.x | ((u64)a.y << 32)) != key.k0 || (s & ~kCacheSlotMask) != tag || !cache_slot(s, rowless_ok, at)) return false;
   r = Row{bits_f32(a.z), bits_f32(a.w), bits_f32(b.x), bits_f32(b.y)};
-  slot = (int64_t)(s & kCacheSlotMask);
+  slot = at;
   return true;
 }
 __device__ __forceinline__ bool cache_get(const RowCache<5>* c, int64_t i, const Geo<5>::Key& key, u64 tag, Row& r,
-                                          int64_t& slot) {
+                                          int64_t& slot, bool rowless_ok = false) {
   const uint4* p = reinterpret_cast<const uint4*>(c + i);
   const uint4 a = p[0], b = p[1], d = p[2];
   const u64 s = (u64)d.x | ((u64)d.y << 32);
-  if (((u64)a.x | ((u64)a.y << 32)) != key.k0 || ((u64)b.z | ((u64)b.w << 32)) != key.k1 || (s & ~kCacheSlotMask) != tag)
+  int64_t at;
+  if (((u64)a.x | ((u64)a.y << 32)) != key.k0 || ((u64)b.z | ((u64)b.w << 32)) != key.k1 || (s & ~kCacheSlotMask) != tag ||
+      !cache_slot(s, rowless_ok, at))
     return false;
   r = Row{bits_f32(a.z), bits_f32(a.w), bits_f32(b.x), bits_f32(b.y)};
-  slot = (int64_t)(s & kCacheSlotMask);
+  slot = at;
   return true;
 }
 __device__ __forceinline__ void cache_put(RowCache<4>* c, int64_t i, const Geo<4>::Key& key, u64 tag, const Row& r,
-                                          int64_t slot) {
-  const u64 k = slot >= 0 ? key.k0 : 0ull;             // no row (table full): nothing to remember
-  const u64 s = ((u64)slot & kCacheSlotMask) | tag;
+                                          int64_t slot, bool rowless = false) {
+  const u64 k = (slot >= 0 || rowless) ? key.k0 : 0ull;   // no row and no visit row: nothing to remember
+  const u64 s = (slot >= 0 ? ((u64)slot & kCacheSlotMask) : kCacheRowless) | tag;
   uint4* p = reinterpret_cast<uint4*>(c + i);
   p[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), f32_bits(r.q0), f32_bits(r.q1));
   p[1] = make_uint4(f32_bits(r.q2), f32_bits(r.q3), (uint32_t)s, (uint32_t)(s >> 32));
 }
 __device__ __forceinline__ void cache_put(RowCache<5>* c, int64_t i, const Geo<5>::Key& key, u64 tag, const Row& r,
-                                          int64_t slot) {
-  const u64 k = slot >= 0 ? key.k0 : 0ull;
-  const u64 s = ((u64)slot & kCacheSlotMask) | tag;
+                                          int64_t slot, bool rowless = false) {
+  const u64 k = (slot >= 0 || rowless) ? key.k0 : 0ull;
+  const u64 s = (slot >= 0 ? ((u64)slot & kCacheSlotMask) : kCacheRowless) | tag;
   uint4* p = reinterpret_cast<uint4*>(c + i);
   p[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), f32_bits(r.q0), f32_bits(r.q1));
   p[1] = make_uint4(f32_bits(r.q2), f32_bits(r.q3), (uint32_t)key.k1, (uint32_t)(key.k1 >> 32));
@@ -868,7 +885,10 @@ __global__ __launch_bounds__(kBlock) void k_q_choose(const q2048_slot* table, u6
     bool made;
     int64_t slot;
     const auto key = state_key(b, salt, status);
-    if (cache == nullptr || !cache_get(cache, i, key, cache_tag(table, mask), r, slot)) probe_find(table, mask, key, r, made);
+    // (closed key set: a rowless record is this env's visit row -- the fresh row of a state without one, as far as
+    // its own invalid moves have taught it)
+    if (cache == nullptr || !cache_get(cache, i, key, cache_tag(table, mask), r, slot, (flags & Q2048_FLAG_NO_NEW_ROWS) != 0u))
+      probe_find(table, mask, key, r, made);
     act = argmax4(r.q0, r.q1, r.q2, r.q3);
   }
   actions[i] = (uint8_t)act;
@@ -934,7 +954,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
       // probe; the defaultdict creates the row when absent, so do we
       Row rs;
       int64_t slot = kNoSlot;
-      if (cache == nullptr || !cache_get(cache, i, key_s, cache_tag(table, mask), rs, slot)) {
+      if (cache == nullptr || !cache_get(cache, i, key_s, cache_tag(table, mask), rs, slot, frozen)) {
         slot = probe_find(table, mask, key_s, rs, ins_s);
         if (slot < 0 && slot != kNoSlot && !frozen) slot = probe_insert(table, mask, key_s, (u64)~slot, ins_s);
       }
@@ -955,12 +975,14 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
         if (same) row_set(rn, act, nq);                  // the row it stays on just changed (:100)
       } else {
         dropped = true;
-        if (!frozen || slot == kNoSlot) atomicOr(status, Q2048_STATUS_TABLE_FULL);
+        if (!frozen) atomicOr(status, Q2048_STATUS_TABLE_FULL);
+        else if (same)   // closed key set: the update lands in the env's visit row (the record below), not in the table
+          row_set(rn, act, td_value(row_get(rs, act), rew, max_next, is_done, lr, gamma));
       }
       bool ins_c = false;
       slot_n = claim_resolve(table, mask, key_n, claim, slot_n, ins_c);
       ins_n = ins_n || ins_c;
-      if (cache != nullptr) cache_put(cache, i, key_n, cache_tag(table, mask), rn, slot_n);
+      if (cache != nullptr) cache_put(cache, i, key_n, cache_tag(table, mask), rn, slot_n, frozen);
     }
     const uint32_t n_ins = wave_count(ins_n) + wave_count(ins_s), n_drop = wave_count(dropped);
     if (tdc.retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)tdc.retries);
@@ -1065,7 +1087,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     // cache when the board is still the one it left -- a coalesced 32-byte read -- else a probe (one
     // scattered 128-byte request per lane: 21.5 us of every launch at 1 Mi boards)
     int64_t slot_s = kNoSlot;
-    if (!play_only && (cache == nullptr || !cache_get(cache, i, key_s, cache_tag(table, mask), q, slot_s)))
+    if (!play_only && (cache == nullptr || !cache_get(cache, i, key_s, cache_tag(table, mask), q, slot_s, frozen)))
       slot_s = probe_find(table, mask, key_s, q, made0);
     Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
@@ -1108,6 +1130,8 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
           pend &= ~(1u << act);
           if (pend) flush_pending(&table[slot_s], q, pend);
         }
+      } else if (frozen) {   // closed key set, no row: the update lands in the visit row `q` (registers) if the env stays
+        nq = td_value(row_get(q, act), o.reward, max_next, o.done != 0, lr, gamma);
       }
       if (o.done) {                                                                    // :103
         // the terminal state's row exists in the reference too (looked up at :41)
@@ -1118,7 +1142,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
           const u64 at = atomicAdd(log_count, 1ull);
           if ((int64_t)at < log_cap) {
             Row ql = q;
-            if (updated && !no_learn) row_set(ql, act, nq);   // the logged row is the live one (:96), post-update
+            if ((updated || frozen) && !no_learn) row_set(ql, act, nq);   // the logged row is the live one (:96), post-update
             q2048_episode rec;
             rec.env_id = id; rec.episode = a.episode; rec.action = (uint8_t)act;
             rec.max_log2 = o.max_log2; rec.steps_lo = (uint16_t)(ctr0 + (uint32_t)t);
@@ -1135,7 +1159,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
         slot_s = play_only ? kNoSlot : probe_find(table, mask, key_s, q, made);
         ins_n = ins_n || made;
       } else if (same) {            // invalid move: same state, its row just changed (:100)
-        if (updated && !no_learn) row_set(q, act, nq);   // (evaluation: the stored row stays as it is)
+        if ((updated || frozen) && !no_learn) row_set(q, act, nq);   // (evaluation: the stored row stays as it is)
         else if (!updated) slot_s = kNoSlot;             // dropped: do not retry the claim with a stale hint
       } else {
         key_s = key_n; slot_s = slot_n; q = qn;                                        // :100
@@ -1161,7 +1185,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     st_aux(aux, i, a);
     // hand the carried row to this env's next launch / choose_action / update_q_value (a state whose
     // row does not exist yet -- an episode began on the last step -- leaves an empty record)
-    if (!play_only && cache != nullptr) cache_put(cache, i, key_s, cache_tag(table, mask), q, slot_s);
+    if (!play_only && cache != nullptr) cache_put(cache, i, key_s, cache_tag(table, mask), q, slot_s, frozen);
 
     if (n_drop && !frozen) atomicOr(status, Q2048_STATUS_TABLE_FULL);   // (frozen: dropping is the caller's policy)
     if (tdc.retries) atomicAdd(&bs.i[Q2048_ST_CAS_RETRY], (u64)tdc.retries);
@@ -1832,6 +1856,9 @@ __global__ __launch_bounds__(kBlock) void k_table_import(q2048_slot* table, u64 
   bool inserted;
   const int64_t slot = probe_insert(table, mask, key, key_home(key, mask), inserted, kMaxProbe);
   if (slot < 0) { atomicOr(status, Q2048_STATUS_TABLE_FULL); return; }
+  // placed beyond the learning paths' probe limit (only at loads above ~0.93): q_lookup / export find the row,
+  // choose / update / the rollouts read it as absent -- the caller is told
+  if (seq_pos(seq_of(key_hash(key), mask), (u64)slot) >= probe_limit(mask, kRolloutProbe)) atomicOr(status, Q2048_STATUS_DEEP_ROW);
   const float4 v = reinterpret_cast<const float4*>(q)[i];
   table[slot].q[0] = v.x; table[slot].q[1] = v.y; table[slot].q[2] = v.z; table[slot].q[3] = v.w;
 }
@@ -2768,7 +2795,7 @@ struct q2048_growth {
   Family* fam = nullptr;
   int prepared = Q2048_PENDING;      // Q2048_PENDING while the worker maps the new table, then Q2048_OK or an error
   double prepare_ms = 0.0;           // what the worker spent on it (reserve + create + map + zero-fill + verify)
-  bool committed = false, verify_count = false;
+  bool committed = false, committing = false, verify_count = false;   // committing: a q2048_table_grow_commit is at work on it
   hipEvent_t moved = nullptr;        // recorded behind the rehash (and the counters' copy) on the caller's stream
 };
 
@@ -2902,10 +2929,17 @@ int q2048_table_grow_commit(q2048_growth* g, int key_words, uint32_t flags, q204
   if (key_words != 1 && key_words != 2) return Q2048_ERR_SIZE;
   if (flags & ~(uint32_t)Q2048_GROW_VERIFY_COUNT) return Q2048_ERR_FLAGS;
   {
+    // ONE critical section decides who commits: the growth must be live and untouched, no other growth of its family
+    // may be committed-and-unfinished (the family's counters are in use until that one is finished) or being
+    // committed right now, and the winner marks `committing` before the lock is released -- two host threads that
+    // commit the same growth, or two growths of one family, cannot both get past this point.  The errors up to here
+    // (NULL, SIZE, FLAGS, BUSY) leave `g` valid: retry later, or q2048_table_grow_abort.
     std::lock_guard<std::mutex> lock(g_growth_mutex);
     if (!growth_is_live(g) || g->committed) return Q2048_ERR_NULL;
-    for (q2048_growth* x : g_growths)                     // the family's counters are in use until that one is finished
-      if (x != g && x->fam == g->fam && x->committed) return Q2048_ERR_BUSY;
+    if (g->committing) return Q2048_ERR_BUSY;
+    for (q2048_growth* x : g_growths)
+      if (x != g && x->fam == g->fam && (x->committed || x->committing)) return Q2048_ERR_BUSY;
+    g->committing = true;
   }
   int rc = wait_prepared(g);
   Family* f = g->fam;
@@ -2941,6 +2975,7 @@ int q2048_table_grow_commit(q2048_growth* g, int key_words, uint32_t flags, q204
   }
   std::lock_guard<std::mutex> lock(g_growth_mutex);
   g->committed = true;
+  g->committing = false;
   *table_out = g->bigger;
   return Q2048_OK;
 }
@@ -2955,7 +2990,10 @@ int q2048_table_grow_finish(q2048_growth* g, int64_t* rows_moved) {
   int rc = Q2048_OK;
   {
     DeviceGuard guard(f->dev);
-    if (hipEventSynchronize(g->moved) != hipSuccess) rc = Q2048_ERR_LAUNCH;
+    // a wait that fails says nothing about the move: the growth stays registered and both tables stay live -- the
+    // caller retries, or frees the NEW table (q2048_table_free finishes what it can and releases it) and carries on
+    // with the old one at its own risk; forgetting `g` here would leave nobody knowing which table holds the rows
+    if (hipEventSynchronize(g->moved) != hipSuccess) return Q2048_ERR_LAUNCH;
   }
   const unsigned long long moved = f->host_scratch[0], failed = f->host_scratch[1], counted = f->host_scratch[2];
   // every occupied slot of the old table must have found its place, and (when asked for) the new table must hold
@@ -3001,7 +3039,12 @@ int q2048_table_grow(q2048_slot* table, int cap_log2, int new_cap_log2, int key_
   q2048_growth* g = nullptr;
   if (int e = q2048_table_grow_begin(table, cap_log2, new_cap_log2, &g)) return e;
   q2048_slot* bigger = nullptr;
-  if (int e = q2048_table_grow_commit(g, key_words, Q2048_GROW_VERIFY_COUNT, &bigger, stream)) return e;
+  if (int e = q2048_table_grow_commit(g, key_words, Q2048_GROW_VERIFY_COUNT, &bigger, stream)) {
+    // BUSY (another growth of the family is committed and unfinished) leaves `g` valid and the prepared table mapped:
+    // this host-synchronous form owns `g`, so it gives both back (any other error has ended the growth already)
+    if (e == Q2048_ERR_BUSY) (void)q2048_table_grow_abort(g);
+    return e;
+  }
   if (int e = q2048_table_grow_finish(g, rows_moved)) {   // the old table is intact and stays the caller's
     (void)unregister_and_release(bigger, false);
     return e;
@@ -3038,7 +3081,10 @@ int q2048_table_free(q2048_slot* table) {
     }
     if (g == nullptr) break;
     if (!committed) (void)q2048_table_grow_abort(g);
-    else (void)q2048_table_grow_finish(g, nullptr);
+    else if (q2048_table_grow_finish(g, nullptr) == Q2048_ERR_LAUNCH) {   // the device is gone: forget the growth, free what there is
+      std::lock_guard<std::mutex> lock(g_growth_mutex);
+      if (growth_is_live(g)) growth_forget(g);
+    }
   }
   Worker::worker().drain();
   Family* f = nullptr;
@@ -3055,7 +3101,25 @@ int q2048_table_free(q2048_slot* table) {
     std::lock_guard<std::mutex> lock(g_tables_mutex);
     for (auto& kv : g_tables) live = live || (kv.second.fam == f && !kv.second.retired);
   }
-  if (!live) (void)release_retired(f->dev, f);
+  if (!live) {
+    (void)release_retired(f->dev, f);
+    // nothing of the family is left (no table, and therefore no growth): its stream and scratch go too
+    bool gone = true;
+    {
+      std::lock_guard<std::mutex> lock(g_tables_mutex);
+      for (auto& kv : g_tables) gone = gone && kv.second.fam != f;
+      if (gone)
+        for (size_t k = 0; k < g_families.size(); ++k)
+          if (g_families[k] == f) { g_families.erase(g_families.begin() + (long)k); break; }
+    }
+    if (gone) {
+      DeviceGuard guard(f->dev);
+      if (f->stream != nullptr) (void)hipStreamDestroy(f->stream);
+      if (f->host_scratch != nullptr) (void)hipHostFree(f->host_scratch);
+      if (f->dev_scratch != nullptr) (void)hipFree(f->dev_scratch);
+      delete f;
+    }
+  }
   return rc;
 }
 

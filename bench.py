@@ -413,7 +413,9 @@ def run_rank(args):
     cpus_before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     pinned = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        pinned = load_launcher().pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")))
+        # (the device this rank will really use: one GPU per local rank, ranks sharing GPUs only in rehearsals on a
+        # smaller box; torch.cuda.device_count() does not initialise the GPU)
+        pinned = load_launcher().pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     pkg = importlib.import_module("2048_q-learning_amd")
     if args.experiment_bits:          # ablation bits exist in the measurement build only
         pkg._native.use_experiments_build()

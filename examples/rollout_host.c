@@ -84,8 +84,9 @@ int main(int argc, char **argv) {
       const int64_t k = steps - done < per_launch ? steps - done : per_launch;
       if (growth != NULL && (int64_t)launches == grow_at) {
         /* the rows move between two launches, on the stream: nothing here waits for them.  Slots change with
-         * the table; the row cache notices by itself (its records carry a tag of the table they came from) */
+         * the table, so the row cache is emptied (the contract; the records' table tag is only a safety net) */
         CHECK_Q(q2048_table_grow_commit(growth, 1, 0, &table, NULL));
+        CHECK_HIP(hipMemsetAsync(cache, 0, (size_t)B * q2048_sizeof_rowcache(4), NULL));
         cap_now += 2;
       }
       CHECK_Q(q2048_fused_rollout_opts(boards, aux, table, cap_now, B, 4, k, eps, 0.1, 0.99, seed, 0,

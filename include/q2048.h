@@ -76,6 +76,10 @@ extern "C" {
 #define Q2048_STATUS_BAD_ACTION 1u    /* an action outside 0..3 was passed (lane left untouched) */
 #define Q2048_STATUS_TILE_OVERFLOW 2u /* a tile above 2^15 does not fit the 64-bit state key */
 #define Q2048_STATUS_TABLE_FULL 4u    /* an update found no slot within the probe limit (dropped) */
+#define Q2048_STATUS_DEEP_ROW 8u      /* q2048_table_import placed a row deeper on its probe sequence than the learning
+                                         paths look (2^10 slots; bulk moves and q2048_q_lookup take 2^14): lookup and
+                                         export find it, choose / update / the rollouts read it as absent.  Only at
+                                         loads above ~0.93: import into a larger table */
 
 /* flags */
 #define Q2048_FLAG_INDEPENDENT 1u /* every env owns private Q rows (key salted by its global id) */
@@ -123,9 +127,21 @@ extern "C" {
                                        - a state without one reads as the zero row the defaultdict would have created
                                          (same greedy action, same bootstrap value 0), and NO row is created for it;
                                        - an update of Q[s][a] whose state has no row is dropped and counted in
-                                         Q2048_ST_DROPS; Q2048_STATUS_TABLE_FULL is NOT raised (the caller asked).
-                                     q2048_q_update / _cached, q2048_fused_rollout*, q2048_det_rollout; ignored by the
-                                     entry points that never create rows (choose, lookup, env, NO_LEARN, PLAY_ONLY).
+                                         Q2048_ST_DROPS; Q2048_STATUS_TABLE_FULL is NOT raised (the caller asked);
+                                       - VISIT ROWS: the dropped update is not lost on the env that made it.  The zero
+                                         row the env read is ITS fresh row for as long as it stays in that state (the
+                                         move was invalid): the update lands there, the env's next choose / update in
+                                         the same state see it, and the row ends when the env moves on or its episode
+                                         ends -- what the defaultdict's fresh row does within one visit (a negative
+                                         reward for action 0 sends argmax on to action 1; without it a greedy env
+                                         repeats an invalid action 0 until the >100-repeats rule ends the episode).
+                                         The fused rollout keeps it in the lane's registers and hands it across
+                                         launches through the row cache (a record without a slot); q_choose_cached /
+                                         q_update_cached likewise.  Without a row cache a visit row ends with the call;
+                                         q2048_det_rollout keeps no per-env row: zeros at every step.
+                                     q2048_q_update / _cached, q2048_q_choose_cached, q2048_fused_rollout*,
+                                     q2048_det_rollout; ignored by the entry points that neither create rows nor read
+                                     the cache (q_choose, lookup, env, NO_LEARN, PLAY_ONLY).
                                      The host decides when: BatchedQLearningAgent(freeze_load=0.5) sets it on every
                                      launch once a table at its largest capacity holds that share of rows */
 
@@ -282,10 +298,11 @@ int q2048_q_update(q2048_slot *table, int cap_log2, const uint8_t *boards_s,
  * and a greedy choose none.  This is what the fused rollout carries in registers, handed over
  * through HBM as a stream; like it, a cached row does not see what OTHER envs wrote to it since.
  * Any calling pattern is correct: a record is used only when its key is the key of the board passed in AND it
- * was left by a call on this very table (every record carries a 24-bit tag of the table's address and capacity:
- * after a growth, or with another table, old records simply miss).  The caller zero-fills the cache when a table
- * is rewritten IN PLACE by other means (zero-filled, imported into, updated through an entry point without the
- * cache): the tag cannot see that. */
+ * was left by a call on this very table.  The contract for that second half: THE CALLER ZERO-FILLS THE CACHE whenever
+ * the table behind it changes -- a growth's commit (slots change), another table, a table rewritten in place
+ * (zero-filled, imported into, updated through an entry point without the cache).  As a safety net every record also
+ * carries a 24-bit tag of the table's address and capacity, so that records of another table miss instead of steering
+ * writes through stale slot indices -- with probability 1 - 2^-24 per pair of tables: a net, not the contract. */
 size_t q2048_sizeof_rowcache(int n);
 int q2048_q_choose_cached(const q2048_slot *table, int cap_log2, const uint8_t *boards, int64_t B,
                           int n, double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr,
@@ -434,10 +451,16 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  *       enqueues the move (k_table_rehash, 18 G rows/s) on `stream`, behind whatever the caller queued on the old
  *       table, and returns the new table WITHOUT waiting for it: every launch queued on `stream` from here on
  *       takes *bigger.  flags: Q2048_GROW_VERIFY_COUNT also counts the new table's rows behind the move (one more
- *       streaming pass, 21 ms per 128 GiB).  On error the old table is intact and still the caller's, g is gone.
+ *       streaming pass, 21 ms per 128 GiB).  Errors: Q2048_ERR_NULL / _SIZE / _FLAGS (arguments) and Q2048_ERR_BUSY
+ *       (another growth of the family is committed and not yet finished, or another thread is committing this very
+ *       growth) change nothing -- g is STILL VALID: retry after the other growth's finish, or q2048_table_grow_abort(g).
+ *       Any other error (the preparation failed: its code; Q2048_ERR_LAUNCH) ends the growth: the old table is intact
+ *       and still the caller's, the prepared table has been released, g is gone.
  *   q2048_table_grow_finish(g, &rows)   waits for the move, checks it -- every occupied slot of the old table found
  *       its place (and, with VERIFY_COUNT, the new table holds exactly that many rows): Q2048_ERR_VERIFY otherwise,
- *       both tables then stay live -- and RETIRES the old table: it is the library's from here on (do not free or
+ *       both tables then stay live and g is gone; Q2048_ERR_LAUNCH when the wait itself failed: nothing is known
+ *       about the move, g stays valid (retry, or free the tables: q2048_table_free resolves the growth) -- and
+ *       RETIRES the old table: it is the library's from here on (do not free or
  *       touch it) and its memory is kept until a mapping on the device finds no room, the family's last live table
  *       is freed, or q2048_table_trim(live table) asks for it -- because memory a process releases is wiped by the
  *       driver at ~40 GB/s before it is handed out again, and the next mapping would wait for that: hipMemCreate of

@@ -18,12 +18,12 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 MAXCELLS = 32
 NO_ACTION = -1
 STREAM_STEP, STREAM_RESET, STREAM_OVER = 0, 1, 2
-ENV_DQN, ENV_RESET_SHAPING = 1, 2     # env_flags of rollout()
+ENV_DQN, ENV_RESET_SHAPING, ENV_NEW_VISITS = 1, 2, 4     # env_flags of rollout()
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE = range(7)
 ST_HIST0, ST_NI = 8, 32
 SF_RETURN, SF_RETURN_SQ, SF_REWARD, SF_NF = 0, 1, 2, 4
 
-# numpy mirror of orc_env_t (96 bytes)
+# numpy mirror of orc_env_t (168 bytes)
 ENV_DTYPE = np.dtype(
     [
         ("board", np.uint8, (MAXCELLS,)),
@@ -38,6 +38,10 @@ ENV_DTYPE = np.dtype(
         ("episode_return", np.float64),
         ("episode", np.uint32),
         ("pad1", np.uint32),
+        ("visit_key", np.uint8, (MAXCELLS,)),      # orc_visit_t: the env's visit row under a closed key set
+        ("visit_q", np.float64, (4,)),
+        ("visit_valid", np.int32),
+        ("visit_pad", np.int32),
     ],
     align=True,
 )
@@ -356,7 +360,8 @@ def rollout(envs: np.ndarray, agent: Agent | None, steps: int, seed: int = 0,
             record: bool = False, env_flags: int = 0):
     """Runs `steps` lockstep steps in place.  Returns (stats_i, stats_f[, acts, rew, done]).
     env_flags: ENV_DQN = the DQN path's env (calculate_reward2, done = game_over),
-    ENV_RESET_SHAPING = resets also restore the shaping state."""
+    ENV_RESET_SHAPING = resets also restore the shaping state, ENV_NEW_VISITS = (closed key set) the envs' visit
+    rows end when the call begins, as on a device launch without a row cache."""
     B = len(envs)
     si = np.zeros(ST_NI, dtype=np.int64)
     sf = np.zeros(SF_NF, dtype=np.float64)

@@ -439,17 +439,18 @@ static int orc_argmax4(const double *q, int n) { /* np.argmax: first maximum */
 
 /* q_table[state]: the defaultdict's lookup (creates the row, Agent/main.py:16) -- or, with the closed key
  * set (orc_agent_t.frozen; not in the reference), the row if it exists and else a zero row that is nobody's */
-static orc_row_t *orc_row_of(orc_agent_t *a, const uint8_t *key) {
-  static const orc_row_t zero_row = {{0}, {0.0, 0.0, 0.0, 0.0}, 0};   /* read only: callers write rows they
-                                                                         got from orc_qtable_get alone */
-  if (!a->frozen) return orc_qtable_get(a->q, key, NULL);
-  orc_row_t *r = orc_qtable_find(a->q, key);
-  return r ? r : (orc_row_t *)&zero_row;
+static const double *orc_row_of(orc_agent_t *a, const uint8_t *key, const orc_visit_t *visit) {
+  static const double zero_row[4] = {0.0, 0.0, 0.0, 0.0};
+  if (!a->frozen) return orc_qtable_get(a->q, key, NULL)->q;
+  const orc_row_t *r = orc_qtable_find(a->q, key);
+  if (r) return r->q;
+  if (visit && visit->valid && memcmp(visit->key, key, ORC_MAXCELLS) == 0) return visit->q;   /* the env's visit row */
+  return zero_row;
 }
 
-/* QLearningAgent.choose_action (:34-38) */
-int orc_agent_choose(orc_agent_t *a, const uint8_t *board, uint32_t draw_eps,
-                     uint32_t draw_act, int *explored) {
+/* QLearningAgent.choose_action (:34-38); `visit`: the env's visit row (closed key set) or NULL */
+static int orc_choose(orc_agent_t *a, const uint8_t *board, uint32_t draw_eps, uint32_t draw_act,
+                      int *explored, const orc_visit_t *visit) {
   if (orc_draw_uniform(draw_eps) < a->epsilon) {           /* :35 */
     if (explored) *explored = 1;
     return orc_draw_action(draw_act);                      /* :36 */
@@ -457,23 +458,45 @@ int orc_agent_choose(orc_agent_t *a, const uint8_t *board, uint32_t draw_eps,
   if (explored) *explored = 0;
   uint8_t key[ORC_MAXCELLS];
   orc_key_of(a, board, key);
-  return orc_argmax4(orc_row_of(a, key)->q, a->action_space);              /* :38 */
+  return orc_argmax4(orc_row_of(a, key, visit), a->action_space);          /* :38 */
+}
+int orc_agent_choose(orc_agent_t *a, const uint8_t *board, uint32_t draw_eps,
+                     uint32_t draw_act, int *explored) {
+  return orc_choose(a, board, draw_eps, draw_act, explored, NULL);
 }
 
-/* QLearningAgent.update_q_value (:40-43) */
-void orc_agent_update(orc_agent_t *a, const uint8_t *s, int action, double reward,
-                      const uint8_t *s2, int done) {
+/* QLearningAgent.update_q_value (:40-43); `visit`: the env's visit row (closed key set) or NULL */
+static void orc_update(orc_agent_t *a, const uint8_t *s, int action, double reward, const uint8_t *s2,
+                       int done, orc_visit_t *visit) {
   uint8_t k1[ORC_MAXCELLS], k2[ORC_MAXCELLS];
   orc_key_of(a, s, k1);
   orc_key_of(a, s2, k2);
-  orc_row_t *rn = orc_row_of(a, k2);
-  int best_next = orc_argmax4(rn->q, a->action_space);                     /* :41 */
-  double qn = rn->q[best_next];
+  const double *rn = orc_row_of(a, k2, visit);
+  int best_next = orc_argmax4(rn, a->action_space);                        /* :41 */
+  double qn = rn[best_next];
   double target = reward + (a->gamma * qn * (double)(1 - (done ? 1 : 0))); /* :42 */
-  if (a->frozen && !orc_qtable_find(a->q, k1)) { a->drops += 1; return; }  /* closed key set: no row, no update */
+  if (a->frozen && !orc_qtable_find(a->q, k1)) {   /* closed key set: no row -- the table is not touched, the update counts as dropped */
+    a->drops += 1;
+    if (visit) {                                   /* ... and lands in the env's visit row, which ends when the env moves on */
+      if (!(visit->valid && memcmp(visit->key, k1, ORC_MAXCELLS) == 0)) {
+        memset(visit, 0, sizeof *visit);
+        memcpy(visit->key, k1, ORC_MAXCELLS);
+        visit->valid = 1;
+      }
+      visit->q[action] += a->lr * (target - visit->q[action]);             /* :43, on the fresh row */
+      if (a->storage_f32) visit->q[action] = (double)(float)visit->q[action];
+      if (done || memcmp(k1, k2, ORC_MAXCELLS) != 0) visit->valid = 0;
+    }
+    return;
+  }
+  if (visit) visit->valid = 0;                     /* (a state with a row has no visit row) */
   orc_row_t *rs = orc_qtable_get(a->q, k1, NULL); /* may grow: rn is dead from here */
   rs->q[action] += a->lr * (target - rs->q[action]);                       /* :43 */
   if (a->storage_f32) rs->q[action] = (double)(float)rs->q[action];        /* float32 table (option) */
+}
+void orc_agent_update(orc_agent_t *a, const uint8_t *s, int action, double reward,
+                      const uint8_t *s2, int done) {
+  orc_update(a, s, action, reward, s2, done, NULL);
 }
 
 /* QLearningAgent.decay_exploration (:45-57) */
@@ -535,6 +558,8 @@ void orc_rollout_ex(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t step
                     uint64_t seed, uint64_t env_id0, uint32_t ctr0, const uint8_t *actions,
                     int64_t *stats_i, double *stats_f, uint8_t *out_actions,
                     double *out_reward, uint8_t *out_done, int env_flags) {
+  if (env_flags & ORC_ENV_NEW_VISITS)
+    for (int64_t i = 0; i < B; ++i) envs[i].visit.valid = 0;
   for (int64_t t = 0; t < steps; ++t) {
     for (int64_t i = 0; i < B; ++i) {
       orc_env_t *e = &envs[i];
@@ -544,7 +569,7 @@ void orc_rollout_ex(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t step
       uint8_t s[ORC_MAXCELLS];
       memcpy(s, e->board, ORC_MAXCELLS);
       int explored = 0, a;
-      if (agent) a = orc_agent_choose(agent, s, x[0], x[1], &explored);   /* main.py:92 */
+      if (agent) a = orc_choose(agent, s, x[0], x[1], &explored, &e->visit);   /* main.py:92 */
       else if (actions) a = actions[t * B + i];
       else { a = orc_draw_action(x[1]); explored = 1; }                   /* random play */
       double r; int done, mx;
@@ -558,7 +583,7 @@ void orc_rollout_ex(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t step
         valid = orc_env_step(e, a, x[2], x[3], &r, &done, &mx);            /* :93 */
       }
       if (agent && agent->storage_f32) r = (double)(float)r; /* the device hands rewards over as float32 */
-      if (agent) orc_agent_update(agent, s, a, r, e->board, done);         /* :99 */
+      if (agent) orc_update(agent, s, a, r, e->board, done, &e->visit);    /* :99 */
       e->episode_return += r;                                              /* :101 */
       if (out_actions) out_actions[t * B + i] = (uint8_t)a;
       if (out_reward) out_reward[t * B + i] = r;
@@ -611,8 +636,8 @@ void orc_rollout_sync(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t st
       const int valid = orc_env_step(e, act[i], x[2], x[3], &r, &done, &mx);   /* :93 */
       uint8_t k2[ORC_MAXCELLS];
       orc_key_of(agent, e->board, k2);
-      const orc_row_t *rn = orc_row_of(agent, k2);                             /* :41 */
-      const double qn = rn->q[orc_argmax4(rn->q, agent->action_space)];
+      const double *rn = orc_row_of(agent, k2, NULL);                          /* :41 */
+      const double qn = rn[orc_argmax4(rn, agent->action_space)];
       const double rf = (double)(float)r;  /* the device hands rewards over as float32 */
       target[i] = rf + (agent->gamma * qn * (double)(1 - (done ? 1 : 0)));     /* :42 */
       e->episode_return += rf;

@@ -30,8 +30,14 @@ def pkg():
     """The product package (directory name is not a Python identifier).  A native library that is missing or older
     than its sources is built first (what __graft_entry__.build() does): a fresh checkout must not fail on that."""
     mod = importlib.import_module("2048_q-learning_amd")
-    mod._native.build()            # no-op when csrc/libq2048_hip.so is newer than its sources
-    mod._native.build_host()       # the CPU twin, likewise
+    mod._native.build_host()       # the CPU twin (g++ only): a no-op when csrc/libq2048_host.so is newer than its sources
+    try:
+        mod._native.hipcc_path()
+    except FileNotFoundError:
+        # a host with neither hipcc nor a GPU runs the CPU-twin and oracle suites all the same; anything that
+        # needs libq2048_hip.so fails loudly when it loads it (`_native.lib()` raises, nothing substitutes for it)
+        return mod
+    mod._native.build()            # likewise for csrc/libq2048_hip.so
     return mod
 
 

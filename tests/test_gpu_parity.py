@@ -1402,55 +1402,79 @@ def test_rollout_on_a_full_table_stays_bounded(pkg, n, freeze):
     assert pkg._native.claim_timeouts(LIB(pkg)) == 0
 
 
-@pytest.mark.parametrize("n,path", [(4, "fused"), (5, "fused"), (4, "four_call"), (5, "four_call"), (4, "strict")])
-def test_closed_key_set_private_rows_match_oracle(pkg, O, n, path):
+@pytest.mark.parametrize("n,path,cache,eps,k1", [(4, "fused", True, 0.3, 50), (5, "fused", True, 0.3, 50),
+                                                  (4, "four_call", True, 0.3, 50), (5, "four_call", True, 0.3, 50),
+                                                  (4, "strict", True, 0.3, 50), (4, "fused", False, 0.3, 50),
+                                                  (4, "four_call", False, 0.3, 50), (4, "fused", True, 0.0, 0),
+                                                  (5, "fused", True, 0.02, 8)])
+def test_closed_key_set_private_rows_match_oracle(pkg, O, n, path, cache, eps, k1):
     """Q2048_FLAG_NO_NEW_ROWS with private rows (every env = one reference agent whose dict stops taking keys after
-    k1 steps: the oracle's `freeze()`): epsilon = 0.3, so the actions depend on the rows AND on absent states reading
-    as the zero row the defaultdict would have created (Agent/main.py:16,38,41).  Boards and aux bit-exact, every row
-    of the closed key set within 1e-5, the key set itself unchanged, drops == the oracle's count of updates whose
-    state has no row, no TABLE_FULL.  Through the fused kernel (also with compare-and-swap TD writes) and the
-    4-call API."""
-    B, k1, k2, seed, id0, eps, lr, gamma = 96, 50, 250, 23, 7000, 0.3, 0.1, 0.99
+    k1 steps: the oracle's `freeze()`).  The actions depend on the rows, on absent states reading as the zero row the
+    defaultdict would have created (Agent/main.py:16,38,41), AND on the env's VISIT ROW: while an env stays in a state
+    without a row its dropped updates land in that fresh row, so an invalid action 0 is followed by action 1 (not by
+    action 0 again until the >100-repeats rule ends the episode).  Boards and aux bit-exact, every row of the closed
+    key set within 1e-5, the key set itself unchanged, drops == the oracle's count of updates whose state has no row,
+    no TABLE_FULL.  Through the fused kernel (split launches: the visit row crosses the cut in the row cache; also with
+    compare-and-swap TD writes) and the 4-call API; `cache` False: no row cache, a visit row ends with the call (the
+    oracle's ENV_NEW_VISITS).  eps = 0 on an EMPTY closed table: pure greedy play on visit rows alone."""
+    B, k2, seed, id0, lr, gamma = 96, 250, 23, 7000, 0.1, 0.99
     env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
     agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
                                       capacity_log2=17, seed=seed, env_id0=id0, device=DEV, independent=True,
-                                      board_size=n, freeze_load=None, strict_td=path == "strict")
+                                      board_size=n, freeze_load=None, strict_td=path == "strict", row_cache=cache)
+    calls = []                                            # the device's calls, for the oracle to repeat
 
     def run(k):
+        if k == 0:
+            return
         if path == "four_call":
             _unfused_loop(pkg, env, agent, k)
+            calls.extend([1] * k)
         else:
-            agent.fused_rollout(env, k // 3)              # (split launches: the flag travels with each)
-            agent.fused_rollout(env, k - k // 3)
+            for part in (k // 3, k - k // 3):             # (split launches: the flag travels with each)
+                if part:
+                    agent.fused_rollout(env, part)
+                    calls.append(part)
 
     run(k1)
+    n1 = len(calls)
     rows1 = agent.table_size()
     agent.frozen = True                                   # the key set is closed by hand (the policy has its own test)
     run(k2)
     envs = O.envs_init(B, n, seed, id0)
-    drops, rows, worst = 0, 0, 0.0
+    oflags = 0 if cache else O.ENV_NEW_VISITS
+    drops, rows, worst, stalled = 0, 0, 0.0, 0
     for i in range(B):
         oa = O.Agent(100, 4, lr, gamma, eps, n=n)
-        O.rollout(envs[i:i + 1], oa, k1, seed, id0 + i, 0)
-        size1 = len(oa)
-        oa.freeze()
-        si, _ = O.rollout(envs[i:i + 1], oa, k2, seed, id0 + i, k1)
-        assert len(oa) == size1 and si[O.ST_DROPS] == oa.drops
+        ctr = 0
+        for c, steps in enumerate(calls):
+            if c == n1:
+                size1 = len(oa)
+                oa.freeze()
+            O.rollout(envs[i:i + 1], oa, steps, seed, id0 + i, ctr, env_flags=oflags)
+            ctr += steps
+        if n1 == 0:
+            size1 = 0
+        assert len(oa) == size1
         drops += oa.drops
         rows += size1
         keys, vals = oa.dump()
-        got, found = agent.q_values(t8(keys), env_id=id0 + i, return_found=True)
-        assert bool(found.all()), i
-        got = got.cpu().numpy()
-        assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), i
-        worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
+        if len(keys):
+            got, found = agent.q_values(t8(keys), env_id=id0 + i, return_found=True)
+            assert bool(found.all()), i
+            got = got.cpu().numpy()
+            assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), i
+            worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
     assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :n * n])
     assert_aux(env.aux_fields(), envs, "closed key set")
     st = agent.stats()
-    print(f"[closed key set {n}x{n} {path}] {rows} rows, {drops} of {B * k2} updates dropped, worst relative Q error {worst:.2e}")
+    print(f"[closed key set {n}x{n} {path} cache={cache} eps={eps}] {rows} rows, {drops} of {B * k2} updates dropped, "
+          f"worst relative Q error {worst:.2e}, longest streak of one action {int(envs['consecutive_count'].max())}")
     assert drops > 0.2 * B * k2                           # most of a 2048 game's states are new
     assert st["drops"] == drops and st["inserts"] == rows == rows1 == agent.table_size()
     assert (path == "four_call" or st["steps"] == B * (k1 + k2)) and agent.check_status() == 0
+    if eps == 0.0:        # greedy play on visit rows: an invalid move teaches the next choice -- nobody repeats one action into the stall rule
+        assert int(envs["consecutive_count"].max()) <= 60 and st["episodes"] > 0   # (valid repeats of one action happen; 100 invalid ones would end the episode)
     assert pkg._native.claim_timeouts(LIB(pkg)) == 0
 
 
@@ -2255,6 +2279,68 @@ def test_table_grows_like_the_reference_defaultdict(pkg, n):
     assert L.q2048_table_grow(af.table.data_ptr(), 24, 25, 1, C.byref(out), C.byref(moved), None) == (
         -2 if getattr(af.table, "_q2048_owner", None) is not None else -1)      # a family of one / not the library's
     assert L.q2048_table_reserve(20, 19, 0, C.byref(out)) == -2 and L.q2048_table_reserve(20, 22, 12345, C.byref(out)) == -2
+
+
+def test_growth_commit_contract_and_two_thread_race(pkg):
+    """q2048_table_grow_commit's error contract and its critical section, through the
+    C ABI alone:
+      * begin(A) -> commit -> begin(B) -> commit(B) BEFORE finish(A): Q2048_ERR_BUSY, and the growth of B is STILL
+        VALID (poll answers, the prepared table is not leaked): after finish(A) the same handle commits;
+      * the host-synchronous q2048_table_grow on a table whose family has an unfinished commit: Q2048_ERR_BUSY, and
+        nothing stays behind -- the next begin on that table works (round 5 left it BUSY until q2048_table_free);
+      * two host threads committing ONE growth while its table is still being mapped: exactly one succeeds, the
+        other gets Q2048_ERR_BUSY (or, had it arrived after the first was done, Q2048_ERR_NULL); the rows are moved once."""
+    import threading
+
+    N, L = pkg._native, LIB(pkg)
+    env = pkg.BatchedGame2048Env(4096, seed=2, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, exploration_rate=1.0, capacity_log2="auto", initial_capacity_log2=18,
+                                      max_capacity_log2=30, prefetch_growth=False, load_limit=0.9, seed=2, device=DEV,
+                                      freeze_load=None)
+    agent.fused_rollout(env, 20)
+    rows = agent.verify_table()["rows"]
+    assert agent.capacity_log2 == 18 and not agent.growths and agent._growth is None and rows > 4096
+    a_ptr, stream = agent.table._q2048_owner.ptr, None
+    g1, g2, b_ptr, c_ptr, moved = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+    sync()
+    assert L.q2048_table_grow_begin(a_ptr, 18, 19, C.byref(g1)) == 0
+    assert L.q2048_table_grow_commit(g1, 1, 0, C.byref(b_ptr), stream) == 0
+    assert L.q2048_table_grow_begin(b_ptr, 19, 20, C.byref(g2)) == 0             # allowed right after the commit
+    assert L.q2048_table_grow_commit(g2, 1, 0, C.byref(c_ptr), stream) == N.ERR_BUSY and not c_ptr.value
+    assert L.q2048_table_grow_wait(g2, None) == 0 and L.q2048_table_grow_poll(g2) == 0    # g2 is alive and prepared
+    g3, d_ptr = C.c_void_p(), C.c_void_p()
+    assert L.q2048_table_grow_begin(b_ptr, 19, 21, C.byref(g3)) == N.ERR_BUSY    # one growth per table: g2
+    assert L.q2048_table_grow_finish(g1, C.byref(moved)) == 0 and moved.value == rows
+    assert L.q2048_table_grow_commit(g2, 1, 0, C.byref(c_ptr), stream) == 0 and c_ptr.value
+    # the synchronous form on C while g2 is committed and unfinished: BUSY, and nothing of it stays behind
+    assert L.q2048_table_grow(c_ptr, 20, 21, 1, C.byref(d_ptr), C.byref(moved), stream) == N.ERR_BUSY
+    assert L.q2048_table_grow_finish(g2, C.byref(moved)) == 0 and moved.value == rows
+    assert L.q2048_table_grow(c_ptr, 20, 21, 1, C.byref(d_ptr), C.byref(moved), stream) == 0 and moved.value == rows
+    # two threads, one growth: 2^21 -> 2^30 slots (32 GiB: tens of milliseconds of mapping, both threads arrive meanwhile)
+    g4, e_ptr = C.c_void_p(), [C.c_void_p(), C.c_void_p()]
+    assert L.q2048_table_grow_begin(d_ptr, 21, 30, C.byref(g4)) == 0
+    codes = [None, None]
+
+    def commit(k):
+        with torch.cuda.device(torch.device(DEV)):
+            codes[k] = L.q2048_table_grow_commit(g4, 1, 0, C.byref(e_ptr[k]), stream)
+
+    threads = [threading.Thread(target=commit, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert sorted(codes)[1] == 0 and sorted(codes)[0] in (N.ERR_BUSY, -1), codes
+    winner = codes.index(0)
+    assert e_ptr[winner].value and not e_ptr[1 - winner].value
+    assert L.q2048_table_grow_finish(g4, C.byref(moved)) == 0 and moved.value == rows      # moved once, every row
+    count = torch.zeros(1, dtype=torch.int64, device=DEV)
+    assert L.q2048_table_count(e_ptr[winner], 30, count.data_ptr(), stream) == 0
+    assert int(count.item()) == rows
+    assert L.q2048_table_free(e_ptr[winner]) == 0          # the family's last live table: its retired ones, stream and scratch go too
+    agent.table._q2048_owner._finalizer.detach()           # (A was retired by finish(g1) and released with its family)
+    del agent
+    print(f"[commit race] codes {codes}: one commit, {rows} rows moved once")
 
 
 def test_growing_table_falls_back_to_a_fixed_one_when_it_cannot_be_mapped(pkg, monkeypatch):

@@ -168,8 +168,12 @@ def train_batched(args, pkg):
     import torch
 
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and args.device != "cpu":
-        # a rank of a multi-GPU job sits on the CPUs next to its GPU (sysfs + sched_setaffinity, no GPU call yet)
-        pkg.launch.pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")))
+        # a rank of a multi-GPU job sits on the CPUs next to ITS GPU -- the device it will really use: the index named
+        # by --device cuda:N, else one GPU per local rank (sysfs + sched_setaffinity, no GPU call yet;
+        # torch.cuda.device_count() does not initialise the GPU)
+        idx = int(args.device.split(":", 1)[1]) if ":" in args.device else (
+            int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        pkg.launch.pin_to_gpu_numa_node(idx)
     rank, local_rank, world = pkg.dist.init_process_group()
     if args.device == "cpu":
         dev = torch.device("cpu")
