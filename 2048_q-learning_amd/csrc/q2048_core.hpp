@@ -40,7 +40,7 @@ constexpr uint32_t kStreamStep = 0u, kStreamReset = 1u, kStreamOver = 2u;
 
 struct Draws { uint32_t x0, x1, x2, x3; };
 
-// (Q2048_PHILOX_ROUNDS: measurement builds only -- tools/sessions/r04_philox7.sh times the rollouts with
+// (Q2048_PHILOX_ROUNDS: measurement builds only -- tools/archive/sessions/r04_philox7.sh times the rollouts with
 // Philox4x32-7, the smallest variant that passes BigCrush, against the 10 rounds of the draw contract.)
 #ifndef Q2048_PHILOX_ROUNDS
 #define Q2048_PHILOX_ROUNDS 10

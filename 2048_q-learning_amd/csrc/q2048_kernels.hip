@@ -493,7 +493,7 @@ __device__ __forceinline__ void stats_flush(BlockStats& s, int64_t* gi, double* 
 // Striped statistics (deterministic step).  A block's flush is one global atomic per non-zero
 // statistic, and with 4096 blocks per one-step launch all of them queue on the same few addresses:
 // at 1 Mi boards that serial tail was 30 of the step's 189 us (statistics pointers NULL: 159 us,
-// tools/exp_stats_cost.py).  So phase 1 adds into one of kStatStripes copies chosen by block index
+// tools/archive/exp_stats_cost.py).  So phase 1 adds into one of kStatStripes copies chosen by block index
 // (64 atomics per address and launch instead of 4096), kept in the caller's workspace, and one small
 // launch at the end of the call folds the copies into the caller's vectors.
 constexpr int kStatStripes = 64;
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step4_pipelined(
 // The 4x4 step of the 4-call API: one board per thread in straight-line code (37 VGPRs, 8 waves
 // per SIMD; more boards per thread with register prefetch measured slower, profiles/r02_env_step.jsonl).  14.7 us per 1 Mi boards = 5.0 TB/s of the 70 B/step, 99.6 us per 8 Mi
 // boards = 5.9 TB/s (94 % of the 6.29 TB/s copy ceiling); a kernel that only moves the same bytes
-// takes 12.07 / 103.5 us (tools/exp_stream_floor.hip).
+// takes 12.07 / 103.5 us (tools/archive/exp_stream_floor.hip).
 template <int ENV>
 __global__ __launch_bounds__(kBlock) void k_env_step4(
     const uint8_t* boards_in, uint8_t* boards, q2048_aux* aux, const uint8_t* actions, int64_t B,
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(kBlock) void k_q_lookup(const q2048_slot* table, u6
 // Workgroups of kUpdateBlock = 1024 lanes: every block ends with one global atomic per non-zero
 // statistic, all on the same few addresses, and in a one-step launch those same-address atomics are
 // a serial tail -- 4096 blocks of 256 cost the launch 15 of its 85 us at 1 Mi boards (statistics
-// pointer NULL: 101 against 116 us per 4-call step, tools/exp_unfused.py UNFUSED_NO_STATS); a
+// pointer NULL: 101 against 116 us per 4-call step, tools/archive/exp_unfused.py UNFUSED_NO_STATS); a
 // quarter as many blocks, a quarter of the tail.  (The fused kernel amortises its flush over K steps:
 // no measurable cost there.)
 constexpr int kUpdateBlock = 1024;
@@ -1030,7 +1030,7 @@ constexpr int kModeLearn = 0, kModeCas = 1, kModeEval = 2, kModeFrozen = 4;
 constexpr int kFusedBlockBig = 512, kFusedBlockSmall = kBlock;
 constexpr int64_t kFusedBigBatch = 786432;
 #ifdef Q2048_EXPERIMENTS
-// Measurement builds only (tools/exp_timeline.py): when set (q2048_debug_timeline), every block of a fused
+// Measurement builds only (tools/archive/exp_timeline.py): when set (q2048_debug_timeline), every block of a fused
 // launch leaves four 100 MHz wall-clock stamps -- in, first step done, last step done, out -- and where it
 // ran (HW_ID: wave / SIMD / CU / SH / SE; XCC_ID) in g_timeline[blockIdx.x * 8 ..]: where in a launch the
 // chip is not full (ramp, rounds, drain), and whether some part of it is slower than the rest.
@@ -2572,7 +2572,7 @@ void* reserve_aligned(size_t bytes, size_t align) {
 // this stack (ROCm 7.2) a range that is freed, reserved again and mapped onto new physical chunks
 // keeps serving some accesses through translations of its previous life: the third table of a
 // process lost 1-15 % of its rows (inserts != occupied slots, 5x5 claims timing out;
-// tools/chunk_debug.py reproduces it in seconds, and with fresh addresses every table is exact).
+// tools/archive/chunk_debug.py reproduces it in seconds, and with fresh addresses every table is exact).
 // Virtual addresses are not scarce (a 32 GiB table uses 2^-12 of a 47-bit space).
 int release_chunks(void* va, size_t chunk, std::vector<hipMemGenericAllocationHandle_t>& handles, size_t mapped) {
   int bad = 0;
@@ -2687,7 +2687,7 @@ int unregister_and_release(q2048_slot* table, bool quiesced) {
   DeviceGuard guard(t.fam->dev);                          // the table's device, whatever the caller's current one is
   if (!quiesced && hipDeviceSynchronize() != hipSuccess) return Q2048_ERR_LAUNCH;
 #ifdef Q2048_EXPERIMENTS
-  // Measurement builds only (tools/chunk_debug.py): the round-3 free path that handed the address range
+  // Measurement builds only (tools/archive/chunk_debug.py): the round-3 free path that handed the address range
   // back, to look for what goes wrong when a range is re-used.  Q2048_DEBUG_VA_FREE = 1: unmap, release,
   // hipMemAddressFree; 2: the same and a device synchronize after it; 3: hipMemAddressFree only after
   // every chunk's hipMemRelease returned success, return codes printed.  Families of one table only.

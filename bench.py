@@ -76,7 +76,7 @@ ALGO_BYTES_ROW_TUPLE = 64 + 8 * 16 + 4 * 4 + 6
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 FREEZE_LOAD = 0.5           # the frozen companion: BatchedQLearningAgent's default freeze_load
-PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r05_pmc_traffic.json", "r05_pmc_traffic_k20.json")]
+PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r06_pmc_traffic.json", "r06_pmc_traffic_k20.json")]
 CSRC = os.path.join(REPO, "2048_q-learning_amd", "csrc")
 KERNEL_SOURCES = ("q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc")
 
@@ -150,7 +150,7 @@ def load_launcher():
 
 def committed_pmc_traffic(cfg: dict):
     """(bytes per env-step, source, None) when one of the committed rocprofv3 PMC profiles
-    (profiles/r05_pmc_traffic*.json: the SURVEY protocol's 64-step launches, the driver's single
+    (profiles/r06_pmc_traffic*.json: the SURVEY protocol's 64-step launches, the driver's single
     20-step launch) was taken with this run's configuration AND on these kernel sources
     (`kernel_sources_sha16`, written by tools/pmc_summary.py on the box that ran the passes), else
     (None, None, what the committed passes were taken with)."""

@@ -887,6 +887,32 @@ def test_bucketised_probing_at_high_load(pkg, n, load):
         assert not bool(found.any()) and float(got.abs().max()) == 0.0
 
 
+def test_import_reports_rows_beyond_the_learning_probe_limit(pkg):
+    """bulk imports place rows up to 2^14 slots down their probe sequence, the learning paths look 2^10
+    slots far.  A table imported to load 0.99 (clusters thousands of slots long) holds such rows: the import says so
+    (Q2048_STATUS_DEEP_ROW; no row is lost: TABLE_FULL stays clear and the count is exact), `q_values` (2^14) finds
+    every row -- and the Python host refuses to load a checkpoint beyond load 0.9 in the first place."""
+    N, L = pkg._native, LIB(pkg)
+    cap_log2, rows = 14, int(0.99 * (1 << 14))
+    rng = np.random.default_rng(11)
+    keys = np.unique(rng.integers(1, 1 << 62, size=2 * rows, dtype=np.int64))[:rows]
+    rng.shuffle(keys)
+    q = rng.standard_normal((rows, 4)).astype(np.float32)
+    agent = pkg.BatchedQLearningAgent(10, capacity_log2=cap_log2, device=DEV)
+    tk, tq = torch.from_numpy(keys.copy()).to(DEV), torch.from_numpy(q).to(DEV)
+    st = torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert L.q2048_table_import(agent.table.data_ptr(), cap_log2, tk.data_ptr(), tq.data_ptr(), rows, 1, st.data_ptr(), None) == 0
+    code = int(st.item())
+    assert code & N.STATUS_DEEP_ROW and not code & N.STATUS_TABLE_FULL and agent.table_size() == rows
+    k = keys.astype(np.uint64)
+    boards = np.stack([((k >> np.uint64(4 * c)) & np.uint64(15)).astype(np.uint8) for c in range(16)], axis=1)
+    got, found = agent.q_values(t8(boards), return_found=True)
+    assert bool(found.all()) and np.array_equal(got.cpu().numpy(), q)
+    fresh = pkg.BatchedQLearningAgent(10, capacity_log2=cap_log2, device=DEV)
+    with pytest.raises(ValueError, match="load factor would exceed 0.9"):
+        fresh.import_rows(keys.astype(np.uint64), q)
+
+
 def test_shared_table_pure_exploration_trajectories_exact(pkg, O):
     """eps = 1: actions come from the draws alone, so every board trajectory is independent of
     the (racy) shared table and must equal the oracle bit for bit at any batch size."""
@@ -1286,6 +1312,54 @@ def test_full_size_1m_lanes_q_dependent_actions(pkg, O, n, cap):
     st = agent.stats()
     assert st["steps"] == B * steps and st["drops"] == 0 and st["cas_retries"] == 0
     assert st["inserts"] == agent.table_size()
+    assert agent.check_status() == 0 and pkg._native.claim_timeouts() == 0
+
+
+@pytest.mark.parametrize("n,cap", [(4, 27), (5, 27)])
+def test_full_size_1m_lanes_closed_key_set(pkg, O, n, cap):
+    """BASELINE configs[2] / [4] at full size with the key set CLOSED after the first launch: 1,048,576 lanes with
+    private rows, eps = 0.2, one 16-step launch of ordinary learning, then three 16-step launches carrying
+    Q2048_FLAG_NO_NEW_ROWS (visit rows cross the launch boundaries in the row cache).  >= 600 sampled lanes against
+    one oracle agent each (`freeze()` after 16 steps): boards and aux bit-exact, every row of the lane's closed key
+    set within 1e-5, and -- over the whole batch -- the table is exactly as large as it was when it closed."""
+    B, seed, id0, eps, lr, gamma, S = 1 << 20, 33, 5, 0.2, 0.1, 0.99, 16
+    env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(1000, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                      capacity_log2=cap, seed=seed, env_id0=id0, device=DEV, independent=True,
+                                      board_size=n, freeze_load=None)
+    agent.fused_rollout(env, S)
+    rows1 = agent.table_size()
+    agent.frozen = True
+    for _ in range(3):
+        agent.fused_rollout(env, S)
+    boards, aux = env.boards.cpu().numpy(), env.aux_fields()
+    rng = np.random.default_rng(100 + n)
+    sample = np.unique(np.concatenate([[0, 1, 63, 64, 511, 512, B - 513, B - 2, B - 1], rng.integers(0, B, size=650)]))
+    assert len(sample) >= 600
+    worst, drops = 0.0, 0
+    for i in sample.tolist():
+        envs = O.envs_init(1, n, seed, id0 + i)
+        oa = O.Agent(1000, 4, lr, gamma, eps, n=n)
+        O.rollout(envs, oa, S, seed, id0 + i, 0)
+        size1 = len(oa)
+        oa.freeze()
+        for k in range(3):
+            O.rollout(envs, oa, S, seed, id0 + i, S * (k + 1))
+        assert len(oa) == size1
+        drops += oa.drops
+        assert boards[i].tolist() == envs["board"][0, :n * n].tolist(), i
+        assert aux["score"][i] == envs["score"][0] and aux["episode"][i] == envs["episode"][0], i
+        assert aux["cons_count"][i] == envs["consecutive_count"][0], i
+        keys, vals = oa.dump()
+        got, found = agent.q_values(t8(keys), env_id=id0 + i, return_found=True)
+        assert bool(found.all()), i
+        got = got.cpu().numpy()
+        assert np.allclose(got, vals, rtol=1e-5, atol=1e-6), i
+        worst = max(worst, float(np.max(np.abs(got - vals) / (np.abs(vals) + 1e-1))))
+    st = agent.stats()
+    print(f"[closed key set {n}x{n} 1M lanes] {len(sample)} lanes, {drops} of {len(sample) * 3 * S} sampled updates dropped, "
+          f"worst relative Q error {worst:.2e}; batch: {rows1} rows, {st['drops']} drops")
+    assert st["steps"] == 4 * B * S and st["inserts"] == rows1 == agent.table_size() and st["drops"] > B
     assert agent.check_status() == 0 and pkg._native.claim_timeouts() == 0
 
 

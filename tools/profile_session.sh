@@ -23,9 +23,9 @@ for extra in "--strict-td" "--eps 0.01 --strict-td" "--steps-per-launch 1 --step
   timeout -k 10 300 python bench.py --cpu-seconds 0 --no-companions $extra 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'args':sys.argv[1]}|{k:d[k] for k in ('value','ms_per_step','region_ms')}|{'frac':d['roofline']['frac'],'ins':d['stats']['inserts_per_step'],'retries':d['stats']['cas_retries'],'drops':d['stats']['drops'],'episodes':d['stats']['episodes']}))" "$extra" | tee -a "$OUT/variants.jsonl"; rc=${PIPESTATUS[0]}; bad $rc && exit 1
 done
 echo "== ablation"
-timeout -k 10 600 python tools/exp_ablate.py 2> /dev/null | tee "$OUT/ablate.jsonl"
+timeout -k 10 600 python tools/archive/exp_ablate.py 2> /dev/null | tee "$OUT/ablate.jsonl"
 echo "== batch sweep"
-timeout -k 10 600 python tools/exp_bsweep.py 2> /dev/null | tee "$OUT/bsweep.jsonl"
+timeout -k 10 600 python tools/archive/exp_bsweep.py 2> /dev/null | tee "$OUT/bsweep.jsonl"
 echo "== train.py"
 timeout -k 10 300 python train.py --num-envs 1 --episodes 3 --log "$OUT/train_single.csv" --summary "$OUT/train_single_summary.csv" 2>&1 | tail -n 2
 timeout -k 10 300 python train.py --num-envs 4096 --episodes 50 --episode-log "$OUT/train_220k_episodes.csv" --summary "$OUT/train_220k_summary.csv" --log "$OUT/train_220k_epochs.csv" 2>&1 | tail -n 2
