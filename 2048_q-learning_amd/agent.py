@@ -1283,10 +1283,12 @@ class QLearningAgent:
         io, b = self._io, self._b
         off = io.take(32)                                        # [0:16] state in, [16] action out
         state_to_log2(state, io.np[off:off + 16])
+        # (the row cache only once the key set is closed: it is what carries the env's visit row from update to choose;
+        # before that the plain entry points are one dependent request shorter for a single env)
         N.check(b._L.q2048_q_choose_cached(
             _ptr(b.table), b.capacity_log2, io.ptr + off, 1, 4, float(b.epsilon), b.seed, b.env_id0,
-            b.ctr & 0xFFFFFFFF, b._learn_flags(), _ptr(b._cache(1)), io.ptr + off + 16, _ptr(b.status),
-            _stream(b.device)), "q_choose")
+            b.ctr & 0xFFFFFFFF, b._learn_flags(), _ptr(b._cache(1)) if b.frozen else None, io.ptr + off + 16,
+            _ptr(b.status), _stream(b.device)), "q_choose")
         b.ctr += 1
         io.sync()
         return int(io.np[off + 16])
@@ -1305,7 +1307,7 @@ class QLearningAgent:
         N.check(b._L.q2048_q_update_cached(
             _ptr(b.table), b.capacity_log2, io.ptr + off, io.ptr + off + 32, io.ptr + off + 36,
             io.ptr + off + 16, io.ptr + off + 33, 1, 4, float(b.lr), float(b.gamma), b.env_id0, b._learn_flags(),
-            _ptr(b._cache(1)), _ptr(b.stats_i), _ptr(b.status), _stream(b.device)), "q_update")
+            _ptr(b._cache(1)) if b.frozen else None, _ptr(b.stats_i), _ptr(b.status), _stream(b.device)), "q_update")
 
     def decay_exploration(self, current_epoch) -> None:
         self._b.decay_exploration(current_epoch)

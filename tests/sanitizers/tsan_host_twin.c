@@ -3,7 +3,8 @@
  * Q values written with relaxed 4-byte atomics), the deterministic step, import / export -- with 4 threads
  * (Q2048_HOST_THREADS).  Built and run by tests/sanitize.sh with -fsanitize=thread (and =address,undefined); exits 0
  * when no row is lost (occupied slots == rows created), the deterministic step with 4 threads equals the one with 1
- * thread bit for bit, and an export / import round trip returns every row. */
+ * thread bit for bit, an export / import round trip returns every row, and a rollout with the key set closed
+ * (Q2048_FLAG_NO_NEW_ROWS, visit rows through a row cache) creates none. */
 #define _POSIX_C_SOURCE 200809L
 #include <stdint.h>
 #include <stdio.h>
@@ -79,6 +80,25 @@ int main(void) {
       CHECK(q2048_q_lookup(t4, CAP, kb, c1, 4, 0, 0, qo, found, &status, NULL));
       for (int64_t r = 0; r < c1; ++r) bad |= !found[r] || memcmp(qo + 4 * r, q1 + 4 * r, 16) != 0;
       free(kb); free(qo); free(found);
+    }
+    /* 4. the closed key set (Q2048_FLAG_NO_NEW_ROWS), 4 threads, the table of leg 1: visit rows travel through the row
+     * cache across two launches; no row is created, every step either updates a row or counts a drop, no TABLE_FULL */
+    {
+      void *cache = zalloc((size_t)B * q2048_sizeof_rowcache(n));
+      q2048_rollout_opts o;
+      memset(&o, 0, sizeof o);
+      o.size = (uint32_t)sizeof o;
+      o.row_cache = cache;
+      int64_t sz[Q2048_NSTAT_I] = {0}, after = 0;
+      uint32_t st2 = 0;
+      CHECK(q2048_fused_rollout_opts(boards, aux, table, CAP, B, n, STEPS / 2, 0.1, 0.1, 0.99, 3, 0, STEPS,
+                                     Q2048_FLAG_NO_NEW_ROWS, sz, NULL, &st2, &o, NULL));
+      CHECK(q2048_fused_rollout_opts(boards, aux, table, CAP, B, n, STEPS / 2, 0.1, 0.1, 0.99, 3, 0, STEPS + STEPS / 2,
+                                     Q2048_FLAG_NO_NEW_ROWS | Q2048_FLAG_TD_CAS, sz, NULL, &st2, &o, NULL));
+      CHECK(q2048_table_count(table, CAP, &after, NULL));
+      bad |= after != count || sz[Q2048_ST_INSERTS] != 0 || sz[Q2048_ST_DROPS] <= 0 || sz[Q2048_ST_DROPS] > (int64_t)B * STEPS ||
+             sz[Q2048_ST_STEPS] != (int64_t)B * STEPS || (st2 & Q2048_STATUS_TABLE_FULL);
+      free(cache);
     }
     free(boards); free(aux); free(table); free(keys); free(q); free(table2);
     free(b1); free(b4); free(a1); free(a4); free(t1); free(t4); free(k1); free(q1);

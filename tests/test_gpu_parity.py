@@ -1066,6 +1066,46 @@ def test_reference_surface_adapters(pkg, O):
     assert str(rows[0]).startswith("[") and float(rows[-1][0]) == got[-1, 0] and rows[5].tolist() == got[5].tolist()
 
 
+def test_adapters_follow_the_table_policy(pkg, O):
+    """The one-env drop-ins on a table far too small for the run (2^9 slots): the reference's loop body goes on
+    unchanged -- the table closes its key set when half of it is in use (checked before every `update_q_value`, as the
+    batched agent does before every launch), unknown states are played on visit rows, and every action, reward and
+    done flag equals the oracle's sequential agent whose dict stops taking keys at the same moment."""
+    import warnings
+
+    seed, eps, steps = 9, 0.1, 1500
+    env = pkg.Game2048_env(device=DEV, seed=seed)
+    agent = pkg.QLearningAgent(100, action_space=4, exploration_rate=eps, discount_factor=0.99, capacity_log2=9,
+                               device=DEV, seed=seed)
+    envs = O.envs_init(1, 4, seed, 0)
+    first = np.asarray(O.draws(seed, 0, 1, O.STREAM_RESET), dtype=np.uint32)
+    O.lib().orc_env_reset(envs.ctypes.data, O._u32(first))
+    envs["episode"][0] = 1
+    oa = O.Agent(100, 4, 0.1, 0.99, eps)
+    state, t, frozen_at = tuple(map(tuple, env.reset())), 0, None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        while t < steps:
+            action = agent.choose_action(state)
+            next_state, reward, done, _ = env.step(action)
+            next_state = tuple(map(tuple, next_state))
+            if frozen_at is None and len(oa) >= 0.5 * (1 << 9):
+                oa.freeze()
+                frozen_at = t
+            _, _, oact, orew, odn = O.rollout(envs, oa, 1, seed, 0, t, record=True)
+            assert (action, bool(done)) == (int(oact[0, 0]), bool(odn[0, 0])), (t, frozen_at)
+            assert abs(reward - float(np.float32(orew[0, 0]))) <= float(ulp32(orew[0, 0])), t
+            agent.update_q_value(state, action, reward, next_state, done)
+            state = tuple(map(tuple, env.reset())) if done else next_state
+            t += 1
+    b = agent._b
+    assert b.frozen and frozen_at is not None and frozen_at < steps // 2 and b.frozen_at["rows"] == len(oa) == len(agent.q_table)
+    assert b.stats()["drops"] == oa.drops > 100 and b.check_status() == 0
+    keys, vals = oa.dump()
+    got = np.stack([np.asarray(agent.q_table[tuple(map(tuple, pkg.boards_to_raw(k)))]) for k in keys])
+    assert np.allclose(got, vals, rtol=1e-5, atol=1e-6)
+
+
 # ---------------------------------------------------------------------------------------------
 # 5x5 boards (BASELINE configs[4]).  The reference hard-codes 4x4; the oracle's n-generic
 # restatement (pinned to the reference at n = 4) is the checker at n = 5.
