@@ -919,7 +919,10 @@ __global__ __launch_bounds__(kBlock) void k_q_lookup(const q2048_slot* table, u6
 // quarter as many blocks, a quarter of the tail.  (The fused kernel amortises its flush over K steps:
 // no measurable cost there.)
 constexpr int kUpdateBlock = 1024;
-template <int N>
+// FROZEN (Q2048_FLAG_NO_NEW_ROWS) is a template parameter: as a run-time flag around `claim_issue` it cost the learning
+// instantiation 7 % (45.8 against 42.6 us per 1 Mi-board call, round-5 tree against this one on one box,
+// profiles/r06_four_call_ab.txt) -- the claim's compare-and-swap lost its overlap with the TD write
+template <int N, bool FROZEN>
 __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u64 mask, const uint8_t* s,
                                                      const uint8_t* actions, const float* reward,
                                                      const uint8_t* s2, const uint8_t* done, int64_t B,
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
     TdCounters tdc{0u, 0u};
     // Q2048_FLAG_NO_NEW_ROWS: the key set is closed -- absent states read as zeros, nothing is claimed, an update
     // of a state without a row is dropped and counted (the caller's policy: no TABLE_FULL)
-    const bool frozen = (flags & Q2048_FLAG_NO_NEW_ROWS) != 0u;
+    constexpr bool frozen = FROZEN;
     if (act > 3) {
       atomicOr(status, Q2048_STATUS_BAD_ACTION);
     } else {
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
       Claim claim{0ull, 0ull, false};
       if (!same) {
         slot_n = probe_find(table, mask, key_n, rn, ins_n);
-        if (!frozen) slot_n = claim_issue(table, mask, slot_n, key_n, claim, ins_n);
+        if constexpr (!frozen) slot_n = claim_issue(table, mask, slot_n, key_n, claim, ins_n);
       }
       const float max_next = max4(rn.q0, rn.q1, rn.q2, rn.q3);
       if (slot >= 0) {
@@ -2224,14 +2227,14 @@ int q2048_q_update_cached(q2048_slot* table, int cap_log2, const uint8_t* boards
   if (!(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
   if (B == 0) return Q2048_OK;
   const u64 mask = (1ull << cap_log2) - 1ull;
-  if (n == 4)
-    hipLaunchKernelGGL(k_q_update<4>, dim3((unsigned)((B + kUpdateBlock - 1) / kUpdateBlock)), dim3(kUpdateBlock), 0, (hipStream_t)stream, table, mask,
-                       boards_s, actions, reward, boards_s2, done, B, lr, gamma, env_id0, flags,
-                       static_cast<RowCache<4>*>(row_cache), stats_i, status);
-  else
-    hipLaunchKernelGGL(k_q_update<5>, dim3((unsigned)((B + kUpdateBlock - 1) / kUpdateBlock)), dim3(kUpdateBlock), 0, (hipStream_t)stream, table, mask,
-                       boards_s, actions, reward, boards_s2, done, B, lr, gamma, env_id0, flags,
-                       static_cast<RowCache<5>*>(row_cache), stats_i, status);
+  const dim3 grid((unsigned)((B + kUpdateBlock - 1) / kUpdateBlock)), block(kUpdateBlock);
+  const hipStream_t s = (hipStream_t)stream;
+#define Q2048_LAUNCH_UPDATE(NN, FR)                                                                                   \
+  hipLaunchKernelGGL((k_q_update<NN, FR>), grid, block, 0, s, table, mask, boards_s, actions, reward, boards_s2, done, \
+                     B, lr, gamma, env_id0, flags, static_cast<RowCache<NN>*>(row_cache), stats_i, status)
+  if (flags & Q2048_FLAG_NO_NEW_ROWS) { if (n == 4) Q2048_LAUNCH_UPDATE(4, true); else Q2048_LAUNCH_UPDATE(5, true); }
+  else { if (n == 4) Q2048_LAUNCH_UPDATE(4, false); else Q2048_LAUNCH_UPDATE(5, false); }
+#undef Q2048_LAUNCH_UPDATE
   return launch_status();
 }
 
