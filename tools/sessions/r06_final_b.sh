@@ -21,4 +21,7 @@ rm -rf $OUT/prof
 timeout -k 10 300 python3 tools/archive/exp_adapters.py 2>/dev/null | tee $OUT/adapters.json
 timeout -k 10 300 python3 tools/archive/exp_unfused.py 2>/dev/null | tee $OUT/four_call.jsonl
 timeout -k 10 300 python3 tools/archive/exp_det.py 2>/dev/null | tee $OUT/deterministic_mode.jsonl
+echo "== fuzz parity (random geometry / batch / splits / 4-call switches / a key set that closes at a random step)"
+FUZZ_PRODUCT=1 timeout -k 10 400 python3 tests/fuzz_parity.py 601 12 2>/dev/null | tail -n 13 | cut -c1-260 | tee $OUT/fuzz_product.txt
+timeout -k 10 400 python3 tests/fuzz_parity.py 602 12 2>/dev/null | tail -n 13 | cut -c1-260 | tee $OUT/fuzz_experiments.txt
 exit 0
