@@ -344,8 +344,9 @@ class BatchedQLearningAgent:
                     created, and its update is dropped and counted (stats['drops']) -- landing in the env's VISIT ROW,
                     which stands in for the missing row while the env stays in that state (so that an invalid move
                     teaches the next greedy choice, as the defaultdict's fresh row would) and ends when it moves on;
-                    a warning says so once and `frozen` is True from then on.  Default 0.5: a 1 Mi-board step on a table frozen there costs what
-                    the young learning table's costs (4x4: 47.3 us against 45.5; 5x5: 61.4 against 61.5), at 0.6 it is
+                    a warning says so once and `frozen` is True from then on.  Default 0.5: a 1 Mi-board step on a
+                    table frozen there costs what the young learning table's costs (4x4: 47.3 us against 45.5; 5x5:
+                    61.4 against 61.5), at 0.6 it is
                     65.9 / 85.5 us, at 0.7 101 / 140, at 0.9 823 / 1206 (profiles/r06_load_curve_frozen*.jsonl), and a
                     table driven to load 1.0 takes 12.9 ms (profiles/r05_claim_first_ab.jsonl).  None: never freeze --
                     the table fills up, probes of absent states walk up to 2^10 slots, and updates that find no slot
