@@ -1938,22 +1938,32 @@ def test_steps_counter_and_argument_checks(pkg):
             -1, 0.5, 0.1, 0.9, 0, 0, 0, 0, None, None, agent.status.data_ptr(), None), "neg steps")
 
 
-@pytest.mark.parametrize("strict", [False, True])
-def test_shared_table_writes_are_legitimate_values(pkg, O, strict):
+@pytest.mark.parametrize("strict,freeze_after", [(False, None), (True, None), (False, 20), (True, 20)])
+def test_shared_table_writes_are_legitimate_values(pkg, O, strict, freeze_after):
     """Shared table, lanes racing on common states.  With lr = 1, gamma = 0 the update writes
     Q[s][a] = reward, so whatever the interleaving every stored value must be EXACTLY one of the
     float32 rewards the oracle saw for that (state, action); untouched entries stay 0; no row may
-    exist for a state the oracle never visited.  (Both write modes: store and compare-and-swap.)"""
+    exist for a state the oracle never visited.  (Both write modes: store and compare-and-swap.)
+    `freeze_after`: the key set closes after that many steps (Q2048_FLAG_NO_NEW_ROWS) -- the racing lanes go on
+    writing legitimate values into the rows that exist, and the table holds exactly the oracle's closed key set."""
     B, steps, seed, id0 = 20000, 60, 33, 400
     env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
     agent = pkg.BatchedQLearningAgent(100, learning_rate=1.0, discount_factor=0.0, exploration_rate=1.0,
-                                      capacity_log2=22, seed=seed, env_id0=id0, device=DEV, strict_td=strict)
-    agent.fused_rollout(env, steps)
+                                      capacity_log2=22, seed=seed, env_id0=id0, device=DEV, strict_td=strict,
+                                      freeze_load=None)
+    if freeze_after is None:
+        agent.fused_rollout(env, steps)
+    else:
+        agent.fused_rollout(env, freeze_after)
+        agent.frozen = True
+        agent.fused_rollout(env, steps - freeze_after)
     envs = O.envs_init(B, 4, seed, id0)
     oa = O.Agent(100, 4, 1.0, 0.0, 1.0)
     shifts = (4 * np.arange(16, dtype=np.uint64))
     seen = {}
     for t in range(steps):
+        if t == freeze_after:
+            oa.freeze()
         keys = (envs["board"][:, :16].astype(np.uint64) << shifts).sum(axis=1)
         si, sf, a, r, d = O.rollout(envs, oa, 1, seed, id0, t, record=True)
         r32 = r[0].astype(np.float32)
@@ -1974,6 +1984,7 @@ def test_shared_table_writes_are_legitimate_values(pkg, O, strict):
             else:
                 bad += float(row[act]) not in vals
     assert bad == 0 and len(dk) == len(oa)
+    assert agent.stats()["drops"] == oa.drops and (oa.drops > 0) == (freeze_after is not None) and agent.check_status() == 0
 
 
 def test_c_host_program_drives_the_abi(pkg, tmp_path):

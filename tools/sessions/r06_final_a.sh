@@ -1,5 +1,7 @@
 #!/usr/bin/env bash
 # round 6, closing session A (final kernel sources): the GPU suite, the 4-call loop against round 5's tree, the counter passes
+# (tools/variants/r05tree was a git worktree of round 5's last commit, 6fb046c, built with `make`: `git worktree add
+# tools/variants/r05tree 6fb046c`; removed again after the session)
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r06y; mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
 # round 6: the 4-call loop of round 5's tree against this round's, alternating, on one box; then per-kernel times of both
+# (tools/variants/r05tree: `git worktree add tools/variants/r05tree 6fb046c && make -C tools/variants/r05tree`; removed afterwards)
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r06f; mkdir -p $OUT
 export TMPDIR=/tmp
