@@ -2551,11 +2551,43 @@ size_t chunk_of(const Family& f, int cap_log2) {
     while (((sizeof(q2048_slot) << cap_log2) + c - 1) / c > kMaxChunks && c < kBigChunk) c <<= 1;
   return c;
 }
-// An address range of `bytes` that starts at a multiple of `align` and has never been mapped.  The
-// reservation's alignment argument is asked for and checked; when the runtime returns less (it honours the
-// granularity only, on this stack) a range one `align` larger is reserved to find room, given back UNMAPPED
-// (no translation of it ever existed: not the trap below) and reserved again at the aligned address inside it.
+// An address range of `bytes` that starts at a multiple of `align` and has never been mapped -- BY ANYBODY.
+//
+// Tables live in a PRIVATE REGION of the address space, handed out once each by a process-wide cursor (16 TiB upward;
+// the runtime's own allocations -- hipMalloc, and the host's mmap -- grow down from the top of the 47-bit space).  Why:
+// q2048_table_free keeps its ranges reserved for ever because a range that is mapped a second time serves stale
+// translations on this stack (below) -- but the same happens with a range ANOTHER allocator has used: after a large
+// hipFree the next un-hinted hipMemAddressReserve returns exactly the freed address (tools/va_hint_probe.hip,
+// profiles/r06_va_hint_probe.jsonl: 64 and 200 GiB, both times): a table reserved the ordinary way right after a
+// framework freed a large tensor sits on a range that has been mapped before.  An address hint in the private region
+// is honoured and a chunk mapped there works (same probe), so no table ever shares a virtual address with anything
+// that was mapped before it, whoever mapped it.
+// When the hint is not honoured (another user of the region, an exotic address-space layout) the reservation falls back
+// to what the runtime offers: the alignment argument is asked for and checked; when the runtime returns less (it honours
+// the granularity only, on this stack) a range one `align` larger is reserved to find room, given back UNMAPPED (no
+// translation of it ever existed) and reserved again at the aligned address inside it.
+// (the measurement build is a second library that tests load into the same process: a region of its own)
+#ifdef Q2048_EXPERIMENTS
+constexpr uintptr_t kPrivateVaBase = (uintptr_t)0x380000000000ull, kPrivateVaEnd = (uintptr_t)0x600000000000ull;
+#else
+constexpr uintptr_t kPrivateVaBase = (uintptr_t)0x100000000000ull, kPrivateVaEnd = (uintptr_t)0x380000000000ull;
+#endif
+std::mutex g_va_mutex;
+uintptr_t g_va_cursor = kPrivateVaBase;
 void* reserve_aligned(size_t bytes, size_t align) {
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    uintptr_t want;
+    {
+      std::lock_guard<std::mutex> lock(g_va_mutex);
+      want = (g_va_cursor + align - 1) / align * align;
+      if (want + bytes > kPrivateVaEnd) break;
+      g_va_cursor = want + bytes + ((uintptr_t)1 << 30);            // (1 GiB of nothing between two tables)
+    }
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, bytes, align, reinterpret_cast<void*>(want), 0) != hipSuccess) continue;
+    if (reinterpret_cast<uintptr_t>(va) == want) return va;
+    (void)hipMemAddressFree(va, bytes);                             // somewhere else: never mapped, given back
+  }
   void* va = nullptr;
   if (hipMemAddressReserve(&va, bytes, align, nullptr, 0) != hipSuccess) return nullptr;
   if (reinterpret_cast<uintptr_t>(va) % align == 0) return va;
@@ -2619,6 +2651,15 @@ int map_table_with(Family* f, int cap_log2, size_t chunk, q2048_slot** out) {
   t.fam = f;
   t.chunk = chunk;
   t.bytes = ((sizeof(q2048_slot) << cap_log2) + chunk - 1) / chunk * chunk;
+  // Room is asked for BEFORE anything is created: a table is never mapped chunk by chunk into a device that cannot hold
+  // it.  Walking the device into exhaustion is not a clean failure on this stack -- hipMemCreate did return an error
+  // when 12 GiB were left for a 64 GiB table, and every chunk was given back, but the NEXT large mapping of the
+  // process (after the memory had been freed again) ended in "Memory access fault by GPU ... Reason: Unknown" during
+  // its zero fill, twice in two runs (profiles/r06_va_reuse_fault.txt).  256 MiB of headroom for the runtime's own needs.
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && t.bytes + ((size_t)256 << 20) > free_b) return Q2048_ERR_ALLOC;
+  }
   char* va = static_cast<char*>(reserve_aligned(t.bytes, chunk));
   if (va == nullptr) return Q2048_ERR_ALLOC;
   const size_t n = t.bytes / t.chunk;

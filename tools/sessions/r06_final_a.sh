@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
-# round 6, closing session A (final kernel sources): the GPU suite, the 4-call loop against round 5's tree, the counter passes
+# round 6, closing session A (final kernel sources): the GPU suite, the counter passes (the 4-call loop against round 5's tree ran in an earlier version
+# of this session: profiles/r06_four_call_ab.txt, tools/sessions/r06_fourcall_ab.sh)
 # (tools/variants/r05tree was a git worktree of round 5's last commit, 6fb046c, built with `make`: `git worktree add
 # tools/variants/r05tree 6fb046c`; removed again after the session)
 cd "$GRAFT_REPO_ROOT"
@@ -7,10 +8,6 @@ OUT=gpurun_out/r06y; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1
 rc=$?; tail -n 4 $OUT/pytest_gpu.txt | cut -c1-300; echo "pytest rc $rc"; [ $rc -eq 0 ] || exit $rc
-for k in 1 2 3; do
-  (cd tools/variants/r05tree && timeout -k 10 200 python3 tools/exp_unfused.py 2>/dev/null | head -n 2 | cut -c1-140 | sed 's/^/r05 /') | tee -a $OUT/four_call_ab.txt
-  timeout -k 10 200 python3 tools/archive/exp_unfused.py 2>/dev/null | head -n 2 | cut -c1-140 | sed 's/^/r06 /' | tee -a $OUT/four_call_ab.txt
-done
 bash tools/pmc_session.sh r06k20 --steps 20 --warmup 5 2>&1 | tail -n 3 | cut -c1-300
 bash tools/pmc_session.sh r06def --cap-log2 32 2>&1 | tail -n 3 | cut -c1-300
 for t in k20 def; do
