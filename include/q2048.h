@@ -494,6 +494,13 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
  * reproducer: tools/va_reuse_repro.hip (152 lines of HIP; profiles/r05_va_reuse_repro.txt: 0 of 8 tables lose
  * rows on fresh ranges, 4 of 8 on a re-used one, 1 of 8 with a device synchronize after the free).  A process
  * therefore accumulates reserved address space -- 2^-12 of its 47-bit space per 32 GiB table -- not memory.
+ * For the same reason tables are reserved in a PRIVATE REGION of the address space (16 TiB upward, one range per table
+ * from a process-wide cursor; the runtime's own allocations grow down from the top): after a large hipFree the next
+ * un-hinted hipMemAddressReserve returns exactly the freed address (tools/va_hint_probe.hip), so a table reserved the
+ * ordinary way could sit on a range some other allocator had mapped before.  And room is asked for (hipMemGetInfo)
+ * before a single chunk is created: Q2048_ERR_ALLOC comes back at once when the device cannot hold the table, because
+ * mapping chunk by chunk until hipMemCreate fails left this stack in a state in which the process's next large mapping
+ * faulted the GPU (profiles/r06_va_reuse_fault.txt).
  * All of these are thread-safe. */
 #define Q2048_GROW_VERIFY_COUNT 1u
 typedef struct q2048_growth q2048_growth; /* opaque: a growth between begin and finish / abort */
