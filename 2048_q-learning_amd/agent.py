@@ -526,6 +526,8 @@ class BatchedQLearningAgent:
         B = boards.shape[0]
         q = torch.empty((B, 4), dtype=torch.float32, device=self.device)
         found = torch.empty(B, dtype=torch.uint8, device=self.device) if return_found else None
+        if B == 0:                               # (an empty batch has no data pointers to hand over)
+            return (q, found.bool()) if return_found else q
         flags = self.flags | (N.FLAG_SINGLE_ENV if env_id is not None else 0)
         N.check(self._L.q2048_q_lookup(
             _ptr(self.table), self.capacity_log2, _ptr(boards), B, self.board_size,
