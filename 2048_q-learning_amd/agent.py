@@ -496,6 +496,8 @@ class BatchedQLearningAgent:
         boards = self._boards(boards)
         B = boards.shape[0]
         actions = torch.empty(B, dtype=torch.uint8, device=self.device)
+        if B == 0:                               # (an empty batch: nothing to choose, and no draw is consumed)
+            return actions
         N.check(self._L.q2048_q_choose_cached(
             _ptr(self.table), self.capacity_log2, _ptr(boards), B, self.board_size, float(self.epsilon),
             self.seed, self.env_id0, self.ctr & 0xFFFFFFFF, self._learn_flags(), _ptr(self._cache(B)), _ptr(actions),
@@ -510,6 +512,8 @@ class BatchedQLearningAgent:
         actions = self._vec(actions, torch.uint8, B, "actions")
         reward = self._vec(reward, torch.float32, B, "reward")
         done = self._vec(done, torch.uint8, B, "done")
+        if B == 0:
+            return
         self._room_for(B)
         N.check(self._L.q2048_q_update_cached(
             _ptr(self.table), self.capacity_log2, _ptr(boards), _ptr(actions), _ptr(reward),

@@ -1934,6 +1934,10 @@ def test_steps_counter_and_argument_checks(pkg):
         agent.q_values(torch.zeros((4, 25), dtype=torch.uint8, device=DEV))
     q0, f0 = agent.q_values(torch.zeros((0, 16), dtype=torch.uint8, device=DEV), return_found=True)   # an empty batch is not an error
     assert tuple(q0.shape) == (0, 4) and tuple(f0.shape) == (0,)
+    none = torch.zeros((0, 16), dtype=torch.uint8, device=DEV)
+    ctr = agent.ctr
+    assert tuple(agent.choose_action(none).shape) == (0,) and agent.ctr == ctr
+    agent.update_q_value(none, none[:, 0], torch.zeros(0, device=DEV), none, none[:, 0])
     with pytest.raises(pkg.NativeError):
         pkg._native.check(LIB(pkg).q2048_fused_rollout(
             env.boards.data_ptr(), env.aux.data_ptr(), agent.table.data_ptr(), agent.capacity_log2, 8, 4,
