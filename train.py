@@ -298,6 +298,11 @@ def train_batched(args, pkg):
         grown = _report_growths(agent, grown, rank)
         print(f"[rank {rank}] table check passed: {check['rows']} rows == rows created, 2^{check['capacity_log2']} "
               f"slots, load {check['load']:.3f}" + (" (frozen)" if agent.frozen else ""), flush=True)
+    # the collectives are over: leave the group in order (a rank that simply exits lets the backend's threads be torn
+    # down under it -- an 8-rank gloo job once ended a rank with "terminate called without an active exception")
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        pkg.dist.barrier()
+        torch.distributed.destroy_process_group()
     return agent
 
 
