@@ -28,6 +28,13 @@ det1 = [r for r in jl(P("profiles", "r06_deterministic_mode.jsonl")) if r["mode"
 ads = f"{json.load(open(P('profiles', 'r06_adapters.json')))['iterations_per_s']:,.0f}".replace(",", " ")
 cb, pc = k20["cpu_baseline"], k20["cpu_baseline"]["product_core"]
 NUM = r"[0-9]+(?:\.[0-9]+)?"
+SUP = str.maketrans("0123456789", "⁰¹²³⁴⁵⁶⁷⁸⁹")
+
+
+def sci(x: float) -> str:
+    """1.07·10⁸: one digit before the point."""
+    e = len(str(int(x))) - 1
+    return f"{x / 10 ** e:.1f}·10" + str(e).translate(SUP)
 
 
 def sub(text, pattern, repl, what):
@@ -56,6 +63,13 @@ s = sub(s, r"the one-env adapters: [0-9 ]+ loop iterations/s", f"the one-env ada
 s = sub(s, rf"\| random reads \+ stable partition \| {NUM} µs per step \(`r06_deterministic_mode\.jsonl`\)",
         f"| random reads + stable partition | {det1:.1f} µs per step (`r06_deterministic_mode.jsonl`)", "DESIGN det")
 s = sub(s, rf"That is 4\.0 GB per\n{NUM} ms launch", f"That is 4.0 GB per\n{l20:.3f} ms launch", "DESIGN launch in the traffic paragraph")
+bt, ot = pc["by_threads"], cb["by_threads"]
+s = sub(s, r"(?s)`cpu_baseline` on the GPU box's host \(2 × EPYC 9575F, `r06_bench_k20\.json`\):.*?(?=\n\n## 6\. Multi-GPU)",
+        (f"`cpu_baseline` on the GPU box's host (2 × EPYC 9575F, `r06_bench_k20.json`): kind `\"port\"` — the oracle, a C port\n"
+         f"of the reference loop: {sci(cb['value'])} env-steps/s on {cb['cores']} threads (private tables; {sci(ot['256'])} on all 256), "
+         f"{sci(cb['single_thread']['value'])} on\none; and `product_core` — the CPU twin, one shared table like the GPU: **{sci(pc['value'])} on {pc['cores']} threads "
+         f"({sci(bt['16'])} on 16,\n{sci(bt['256'])} on 256), {sci(pc['single_thread']['value'])} on one**. Reference CPython: 1.1·10⁴. The GPU line is "
+         f"{k20['value'] / pc['value']:.0f} × the product's own code on\nthe host's best thread count."), "DESIGN cpu baseline")
 open(P("DESIGN.md"), "w", encoding="utf-8").write(s)
 
 # ---- README.md ----------------------------------------------------------------------------------------------------
@@ -66,9 +80,9 @@ s = sub(s, rf"default command \(64-step launches, 128 GiB table\): \*\*{NUM}·10
         f"default command (64-step launches, 128 GiB table): **{vd:.2f}·10¹⁰ env-steps/s, {fd:.3f}**", "README default")
 s = sub(s, rf"the bench's frozen-table companion: {NUM}·10¹⁰, {NUM} µs per step, {NUM};",
         f"the bench's frozen-table companion: {fz20['value'] / 1e10:.2f}·10¹⁰, {fz20['ms_per_step'] * 1e3:.1f} µs per step, {fz20['roofline_frac']:.3f};", "README frozen")
-s = sub(s, rf"the oracle \(C port of the reference\): {NUM}·10⁶ on one thread, {NUM}·10⁷ on \d+; \*\*the product's own CPU twin\*\* \(([^)]*)\): {NUM}·10⁶ on one thread, {NUM}·10⁷ on \d+",
-        lambda m: (f"the oracle (C port of the reference): {cb['single_thread']['value'] / 1e6:.1f}·10⁶ on one thread, {cb['value'] / 1e7:.1f}·10⁷ on {cb['cores']}; "
-                   f"**the product's own CPU twin** ({m.group(1)}): {pc['single_thread']['value'] / 1e6:.1f}·10⁶ on one thread, {pc['value'] / 1e7:.1f}·10⁷ on {pc['cores']}"),
+s = sub(s, rf"the oracle \(C port of the reference\): {NUM}·10[⁰-⁹]+ on one thread, {NUM}·10[⁰-⁹]+ on \d+; \*\*the product's own CPU twin\*\* \(([^)]*)\): {NUM}·10[⁰-⁹]+ on one thread, {NUM}·10[⁰-⁹]+ on \d+",
+        lambda m: (f"the oracle (C port of the reference): {sci(cb['single_thread']['value'])} on one thread, {sci(cb['value'])} on {cb['cores']}; "
+                   f"**the product's own CPU twin** ({m.group(1)}): {sci(pc['single_thread']['value'])} on one thread, {sci(pc['value'])} on {pc['cores']}"),
         "README cpu baselines")
 s = sub(s, rf"\| 5×5 boards, 1,048,576 envs \| {NUM}–{NUM}·10¹⁰ env-steps/s \({NUM} on 156 B/step",
         f"| 5×5 boards, 1,048,576 envs | {c5['value'] / 1e10:.2f}–{c5d['value'] / 1e10:.2f}·10¹⁰ env-steps/s ({c5['roofline_frac']:.3f} on 156 B/step", "README 5x5")
