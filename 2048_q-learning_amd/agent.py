@@ -592,7 +592,7 @@ class BatchedQLearningAgent:
         return m[:N.NSTAT_I].copy(), m[N.NSTAT_I:N.NSTAT_I + N.NSTAT_F].view(np.float64).copy()
 
     def deterministic_rollout(self, env: BatchedGame2048Env, steps: int) -> None:
-        """Reproducible shared-table training (q2048_det_rollout): per step every env acts on the
+        """Reproducible shared-table training (q2048_det_rollout_cached): per step every env acts on the
         table as it is at the start of the step, the updates are sorted on the device by a hash of
         (state, action) and each group is applied update by update in env order.  The result is a
         function of the inputs alone and equals the reference agent (with float32 rows) fed the same
@@ -612,12 +612,16 @@ class BatchedQLearningAgent:
             ws = self._det_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = (ws.data_ptr() + 255) & ~255                       # the workspace is 256-byte aligned
         self._room_for(B * int(steps))
-        self.invalidate_row_cache()
-        N.check(L.q2048_det_rollout(
+        # closed key set: the envs' visit rows live in the row cache from step to step (and come from / go on to
+        # fused_rollout and update_q_value in it); otherwise this step neither reads nor keeps the records valid
+        cache = self._cache(B) if self.frozen else None
+        if cache is None:
+            self.invalidate_row_cache()
+        N.check(L.q2048_det_rollout_cached(
             _ptr(env.boards), _ptr(env.aux), _ptr(self.table), self.capacity_log2, B, self.board_size,
             int(steps), float(self.epsilon), float(self.lr), float(self.gamma), self.seed, self.env_id0,
             self.ctr & 0xFFFFFFFF, self._learn_flags() | env.env_flags | self.experiment_bits, _ptr(self.stats_i),
-            _ptr(self.stats_f), _ptr(self.status), base, need, _stream(self.device)), "det_rollout")
+            _ptr(self.stats_f), _ptr(self.status), base, need, _ptr(cache), _stream(self.device)), "det_rollout")
         env.ctr += int(steps)
         self.ctr += int(steps)
 

@@ -621,9 +621,10 @@ void fused_rollout_n(uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mas
 template <int N>
 void det_rollout_n(uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, int64_t steps, double eps,
                    double lr, double gamma, uint64_t seed, uint64_t env_id0, uint32_t ctr0, uint32_t flags,
-                   int64_t* stats_i, double* stats_f, uint32_t* status) {
+                   int64_t* stats_i, double* stats_f, uint32_t* status, void* row_cache) {
   const int env = env_bits(flags);
   const bool create = (flags & Q2048_FLAG_NO_NEW_ROWS) == 0;
+  void* const cache = create ? nullptr : row_cache;   // visit rows: closed key set only
   std::vector<int64_t> cell((size_t)B);          // slot * 4 + action, or -1 (dropped)
   std::vector<double> target((size_t)B);
   int64_t* cp = cell.data();
@@ -650,10 +651,20 @@ void det_rollout_n(uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask,
         const int64_t slot_s = find_or_create(table, mask, key_s, q, ins_s, create);
         const bool dropped = slot_s < 0;
         if (dropped) { q = Row{0.f, 0.f, 0.f, 0.f}; if (create || slot_s == kNoSlot) status_or(status, Q2048_STATUS_TABLE_FULL); }
+        if (dropped) visit_get<N>(cache, i, table, mask, key_s, q);                          // the env's visit row
         const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);       // :92
         const StepOut o = env_step_any(env, b, a, act, x.x2, x.x3, y.x0, y.x1);              // :93
         const auto key_n = state_key(b, salt, status);
         find_or_create(table, mask, key_n, qn, ins_n, create);                               // :41
+        if (cache != nullptr) {
+          // a visit row is one env's: its update needs no ordering and is applied here, not by phase 2
+          const bool stays = dropped && key_eq(key_n, key_s);
+          if (stays) qn = q;
+          Row v = q;
+          if (stays && !o.done)
+            row_set(v, act, td_value(row_get(q, act), o.reward, max4(qn.q0, qn.q1, qn.q2, qn.q3), false, lr, gamma));
+          visit_put<N>(cache, i, table, mask, key_s, v, stays && !o.done);
+        }
         cp[i] = dropped ? -1 : slot_s * 4 + act;
         tp[i] = td_target(o.reward, max4(qn.q0, qn.q1, qn.q2, qn.q3), o.done != 0, gamma);   // :42
         st.i[Q2048_ST_STEPS] += 1;
@@ -906,8 +917,16 @@ int64_t q2048_det_workspace_bytes(int64_t B, int cap_log2) {
 int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2, int64_t B, int n,
                       int64_t steps, double eps, double lr, double gamma, uint64_t seed, uint64_t env_id0,
                       uint32_t ctr0, uint32_t flags, int64_t* stats_i, double* stats_f, uint32_t* status,
-                      void* workspace, int64_t workspace_bytes, void*) {
+                      void* workspace, int64_t workspace_bytes, void* stream) {
+  return q2048_det_rollout_cached(boards, aux, table, cap_log2, B, n, steps, eps, lr, gamma, seed, env_id0, ctr0, flags,
+                                  stats_i, stats_f, status, workspace, workspace_bytes, nullptr, stream);
+}
+int q2048_det_rollout_cached(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2, int64_t B, int n,
+                             int64_t steps, double eps, double lr, double gamma, uint64_t seed, uint64_t env_id0,
+                             uint32_t ctr0, uint32_t flags, int64_t* stats_i, double* stats_f, uint32_t* status,
+                             void* workspace, int64_t workspace_bytes, void* row_cache, void*) {
   if (int e = check_batch(B, n)) return e;
+  if (row_cache != nullptr && !aligned16(row_cache)) return Q2048_ERR_ALIGN;
   if (int e = check_flags(flags, Q2048_FLAG_NO_LEARN | Q2048_FLAG_PLAY_ONLY)) return e;
   if (B > 0x7fffffffll) return Q2048_ERR_SIZE;
   if (int e = check_table(table, cap_log2)) return e;
@@ -917,8 +936,8 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   if (!(eps >= 0.0 && eps <= 1.0) || !(lr == lr) || !(gamma == gamma)) return Q2048_ERR_RANGE;
   if (B == 0 || steps == 0) return Q2048_OK;
   const u64 mask = (1ull << cap_log2) - 1ull;
-  if (n == 4) det_rollout_n<4>(boards, aux, table, mask, B, steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status);
-  else det_rollout_n<5>(boards, aux, table, mask, B, steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status);
+  if (n == 4) det_rollout_n<4>(boards, aux, table, mask, B, steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status, row_cache);
+  else det_rollout_n<5>(boards, aux, table, mask, B, steps, eps, lr, gamma, seed, env_id0, ctr0, flags, stats_i, stats_f, status, row_cache);
   return Q2048_OK;
 }
 

@@ -1237,11 +1237,16 @@ __device__ __forceinline__ Row ld_row(const q2048_slot* s) {
 }
 // 4x4: 8 waves per SIMD (64 VGPRs, 3 dwords of scratch) measures 165.0 us per 1 Mi-board step against
 // 167.9 at the unconstrained 65 VGPRs / 7 waves; 5x5 would spill 8-17 dwords for it and keeps 7
-template <int N, int ENV>
-__global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
+// VISITS (q2048_det_rollout_cached with the key set closed): the envs' VISIT ROWS -- the two-phase step keeps no row in
+// registers from one step to the next, so an env's visit row lives in its row-cache record (a record without a slot,
+// the fused rollout's and the 4-call API's format: the three paths hand visit rows to one another).  Its own
+// instantiation: in the learning step the extra live values cost the 5x5 body 13 dwords of scratch.
+template <int N, int ENV, bool VISITS>
+__device__ __forceinline__ void det_phase1_body(
     uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
     uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, double* target_out,
-    uint32_t* carry, int use_carry, StatStripe* stat_stripes, uint32_t* gs0, int n_gs, uint32_t* status) {
+    uint32_t* carry, int use_carry, StatStripe* stat_stripes, uint32_t* gs0, int n_gs, uint32_t* status,
+    RowCache<N>* cache, double lr) {
   __shared__ BlockStats bs;
   __shared__ Stage<N> st;
   stats_clear(bs);
@@ -1264,6 +1269,7 @@ __global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
     // (rows never move), so there is no probe -- and the row itself is needed by greedy lanes only
     // (at epsilon 0.95: one scattered request per step less for 19 lanes of 20)
     const uint32_t held = use_carry ? carry[i] : kNoCarry;
+    constexpr bool visits = VISITS;
     int64_t slot_s;
     if (held != kNoCarry) {
       slot_s = (int64_t)held;
@@ -1272,6 +1278,13 @@ __global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
       slot_s = probe_find(table, mask, key_s, q, ins_s);
       if (slot_s < 0 && slot_s != kNoSlot && !frozen) slot_s = probe_insert(table, mask, key_s, (u64)~slot_s, ins_s);
       if (slot_s < 0) { dropped = true; if (!frozen || slot_s == kNoSlot) atomicOr(status, Q2048_STATUS_TABLE_FULL); }
+      if constexpr (visits) {
+        if (slot_s < 0) {                                // no row: the env's visit row, as far as it has one
+          Row v;
+          int64_t at;
+          if (cache_get(cache, i, key_s, cache_tag(table, mask), v, at, true) && at == kNoSlot) q = v;
+        }
+      }
     }
     bool explored;
     const int act = eps_greedy(eps, x.x0, x.x1, q.q0, q.q1, q.q2, q.q3, explored);     // main.py:92
@@ -1279,6 +1292,21 @@ __global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
     const auto key_n = state_key(b, salt, status);
     int64_t slot_n = probe_find(table, mask, key_n, qn, ins_n);                         // :41
     if (slot_n < 0 && slot_n != kNoSlot && !frozen) slot_n = probe_insert(table, mask, key_n, (u64)~slot_n, ins_n);
+    if constexpr (visits) {
+      // closed key set: an env that stays in a state without a row (an invalid move) bootstraps from, and updates,
+      // its own visit row -- private to the env, so it is applied here and not by the grouped phase 2; every other
+      // env leaves an empty record (also what clears the records a fused launch left: `use_carry` == 0 is the
+      // call's first step)
+      const bool same = key_eq(key_n, key_s);
+      if (dropped && same) qn = q;
+      if (dropped && same && !o.done) {
+        Row v = q;
+        row_set(v, act, td_value(row_get(q, act), o.reward, max4(qn.q0, qn.q1, qn.q2, qn.q3), false, lr, gamma));
+        cache_put(cache, i, key_s, cache_tag(table, mask), v, kNoSlot, true);
+      } else if (dropped || !use_carry) {
+        cache_put(cache, i, key_s, cache_tag(table, mask), q, kNoSlot, false);
+      }
+    }
     carry[i] = (!o.done && slot_n >= 0 && (u64)slot_n < (u64)kNoCarry) ? (uint32_t)slot_n : kNoCarry;
     // the group of this update: (slot of s, action), sorted by a hash of (s, action).  The sort is
     // stable and this array is in env order, so env order survives without an index
@@ -1313,6 +1341,24 @@ __global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
   }
   store_board(boards, i, B, b, st);
   stats_flush_striped(bs, stat_stripes);
+}
+
+template <int N, int ENV>
+__global__ __launch_bounds__(kBlock, N == 4 ? 8 : 7) void k_det_phase1(
+    uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
+    uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, double* target_out,
+    uint32_t* carry, int use_carry, StatStripe* stat_stripes, uint32_t* gs0, int n_gs, uint32_t* status) {
+  det_phase1_body<N, ENV, false>(boards, aux, table, mask, B, eps, gamma, seed, env_id0, ctr, flags, group_out, target_out,
+                                 carry, use_carry, stat_stripes, gs0, n_gs, status, nullptr, 0.0);
+}
+template <int N, int ENV>
+__global__ __launch_bounds__(kBlock, 7) void k_det_phase1_visits(
+    uint8_t* boards, q2048_aux* aux, q2048_slot* table, u64 mask, int64_t B, double eps, double gamma,
+    uint64_t seed, uint64_t env_id0, uint32_t ctr, uint32_t flags, u64* group_out, double* target_out,
+    uint32_t* carry, int use_carry, StatStripe* stat_stripes, uint32_t* gs0, int n_gs, uint32_t* status,
+    void* row_cache, double lr) {
+  det_phase1_body<N, ENV, true>(boards, aux, table, mask, B, eps, gamma, seed, env_id0, ctr, flags, group_out, target_out,
+                                carry, use_carry, stat_stripes, gs0, n_gs, status, static_cast<RowCache<N>*>(row_cache), lr);
 }
 
 // The sort: least-significant-digit radix passes of 8 bits over (group, target) pairs, each pass a
@@ -2348,7 +2394,17 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
                       uint64_t env_id0, uint32_t ctr0, uint32_t flags, int64_t* stats_i,
                       double* stats_f, uint32_t* status, void* workspace, int64_t workspace_bytes,
                       void* stream) {
+  return q2048_det_rollout_cached(boards, aux, table, cap_log2, B, n, steps, eps, lr, gamma, seed, env_id0, ctr0, flags,
+                                  stats_i, stats_f, status, workspace, workspace_bytes, nullptr, stream);
+}
+
+int q2048_det_rollout_cached(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int cap_log2, int64_t B, int n,
+                             int64_t steps, double eps, double lr, double gamma, uint64_t seed,
+                             uint64_t env_id0, uint32_t ctr0, uint32_t flags, int64_t* stats_i,
+                             double* stats_f, uint32_t* status, void* workspace, int64_t workspace_bytes,
+                             void* row_cache, void* stream) {
   if (int e = check_batch(B, n)) return e;
+  if (row_cache != nullptr && !aligned16(row_cache)) return Q2048_ERR_ALIGN;
   // no learner-less or evaluation form of the deterministic step: refuse rather than learn anyway
   if (int e = check_flags(flags, Q2048_FLAG_NO_LEARN | Q2048_FLAG_PLAY_ONLY)) return e;
   if (B > 0x7fffffffll) return Q2048_ERR_SIZE;                       // one sort of at most 2^31 updates
@@ -2385,9 +2441,15 @@ int q2048_det_rollout(uint8_t* boards, q2048_aux* aux, q2048_slot* table, int ca
   const u64 run_mask = ((1ull << sort_hi) - 1ull) & ~((1ull << sort_lo) - 1ull);
   if (Q2048_XBITS(flags, 14, 1u)) L.n_groups = 0;   // experiment builds: the partition with its scan launch (the path of batches > 8 Mi)
   for (int64_t t = 0; t < steps; ++t) {
-    Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
-                     ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), stripes, gs[0],
-                     L.n_groups * kBlock, status);
+    if (row_cache != nullptr && (flags & Q2048_FLAG_NO_NEW_ROWS) != 0u) {
+      Q2048_LAUNCH_ENV(k_det_phase1_visits, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
+                       ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), stripes, gs[0],
+                       L.n_groups * kBlock, status, row_cache, lr);
+    } else {
+      Q2048_LAUNCH_ENV(k_det_phase1, flags, n, B, s, boards, aux, table, mask, B, eps, gamma, seed, env_id0,
+                       ctr0 + (uint32_t)t, flags, group[0], target[0], carry, (int)(t > 0), stripes, gs[0],
+                       L.n_groups * kBlock, status);
+    }
     int cur = 0;                                     // which buffer holds the pairs
     for (int lo = sort_lo, pass = 0; lo < sort_hi; lo += 8, cur ^= 1, ++pass) {
       const uint32_t dmask = sort_hi - lo >= 8 ? 255u : (1u << (sort_hi - lo)) - 1u;

@@ -137,10 +137,12 @@ extern "C" {
                                          repeats an invalid action 0 until the >100-repeats rule ends the episode).
                                          The fused rollout keeps it in the lane's registers and hands it across
                                          launches through the row cache (a record without a slot); q_choose_cached /
-                                         q_update_cached likewise.  Without a row cache a visit row ends with the call;
-                                         q2048_det_rollout keeps no per-env row: zeros at every step.
+                                         q_update_cached likewise, and q2048_det_rollout_cached keeps it in the row
+                                         cache from step to step (one record format: the three paths hand visit rows to
+                                         one another).  Without a row cache a visit row ends with the call -- in
+                                         q2048_det_rollout, whose step keeps nothing per env, with the step.
                                      q2048_q_update / _cached, q2048_q_choose_cached, q2048_fused_rollout*,
-                                     q2048_det_rollout; ignored by the entry points that neither create rows nor read
+                                     q2048_det_rollout(_cached); ignored by the entry points that neither create rows nor read
                                      the cache (q_choose, lookup, env, NO_LEARN, PLAY_ONLY).
                                      The host decides when: BatchedQLearningAgent(freeze_load=0.5) sets it on every
                                      launch once a table at its largest capacity holds that share of rows */
@@ -411,6 +413,18 @@ int q2048_det_rollout(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int ca
                       uint64_t env_id0, uint32_t ctr0, uint32_t flags, int64_t *stats_i,
                       double *stats_f, uint32_t *status, void *workspace, int64_t workspace_bytes,
                       void *stream);
+/* ... with the envs' row cache (B records of q2048_sizeof_rowcache(n) bytes, 16-byte aligned, the one the fused
+ * rollout and the _cached calls take; NULL = q2048_det_rollout).  Used with Q2048_FLAG_NO_NEW_ROWS only, for VISIT
+ * ROWS: an env in a state without a row reads its visit row in phase 1, and while it stays there its update --
+ * dropped from the table and counted as before -- lands in that row (float32, the fused rollout's arithmetic; it is
+ * one env's, so it needs no ordering and the result stays a function of the inputs alone).  Every record the call
+ * touches is left either a visit row or empty: records of table rows left by a fused launch are cleared, never
+ * used.  Without the flag the cache is neither read nor written. */
+int q2048_det_rollout_cached(uint8_t *boards, q2048_aux *aux, q2048_slot *table, int cap_log2, int64_t B,
+                             int n, int64_t steps, double eps, double lr, double gamma, uint64_t seed,
+                             uint64_t env_id0, uint32_t ctr0, uint32_t flags, int64_t *stats_i,
+                             double *stats_f, uint32_t *status, void *workspace, int64_t workspace_bytes,
+                             void *row_cache, void *stream);
 
 /* Table allocation from small physical chunks -- the ONLY entry points that allocate (everything
  * else works on caller-owned memory, however it was obtained; a table from hipMalloc / a framework

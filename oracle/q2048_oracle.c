@@ -631,15 +631,31 @@ void orc_rollout_sync(orc_env_t *envs, int64_t B, orc_agent_t *agent, int64_t st
       uint8_t *s = s_all + i * ORC_MAXCELLS;
       memcpy(s, e->board, ORC_MAXCELLS);
       int explored = 0;
-      act[i] = orc_agent_choose(agent, s, x[0], x[1], &explored);            /* main.py:92 */
+      act[i] = orc_choose(agent, s, x[0], x[1], &explored, &e->visit);       /* main.py:92 */
       double r; int done, mx;
       const int valid = orc_env_step(e, act[i], x[2], x[3], &r, &done, &mx);   /* :93 */
-      uint8_t k2[ORC_MAXCELLS];
+      uint8_t k1[ORC_MAXCELLS], k2[ORC_MAXCELLS];
+      orc_key_of(agent, s, k1);
       orc_key_of(agent, e->board, k2);
-      const double *rn = orc_row_of(agent, k2, NULL);                          /* :41 */
+      const double *rn = orc_row_of(agent, k2, &e->visit);                     /* :41 */
       const double qn = rn[orc_argmax4(rn, agent->action_space)];
       const double rf = (double)(float)r;  /* the device hands rewards over as float32 */
       target[i] = rf + (agent->gamma * qn * (double)(1 - (done ? 1 : 0)));     /* :42 */
+      /* closed key set: a state without a row learns in the env's visit row, as in orc_update -- private to the env,
+       * so it needs no ordering and is applied here; phase 2 counts the update as dropped */
+      if (agent->frozen && !orc_qtable_find(agent->q, k1)) {
+        orc_visit_t *v = &e->visit;
+        if (!(v->valid && memcmp(v->key, k1, ORC_MAXCELLS) == 0)) {
+          memset(v, 0, sizeof *v);
+          memcpy(v->key, k1, ORC_MAXCELLS);
+          v->valid = 1;
+        }
+        v->q[act[i]] += agent->lr * (target[i] - v->q[act[i]]);
+        if (agent->storage_f32) v->q[act[i]] = (double)(float)v->q[act[i]];
+        if (done || memcmp(k1, k2, ORC_MAXCELLS) != 0) v->valid = 0;
+      } else {
+        e->visit.valid = 0;
+      }
       e->episode_return += rf;
       if (stats_i) {
         stats_i[ORC_ST_STEPS] += 1; stats_i[ORC_ST_VALID] += (valid > 0);

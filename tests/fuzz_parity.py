@@ -2,8 +2,8 @@
 """Confidence run (not part of the test suite): the independent-lane parity check of
 tests/test_gpu_parity.py over more seeds, both geometries, every env profile, deferred writes on and
 off, random launch splits, and -- for a third of the cases -- the 4-call API (choose_action, step into
-the other board buffer, update_q_value with the row cache, reset(done)) instead of the fused rollout,
-switching between the two in mid-run -- and, for half of the cases, a key set that CLOSES at a random step
+the other board buffer, update_q_value with the row cache, reset(done)) and the deterministic step instead of the
+fused rollout, switching between the three in mid-run -- and, for half of the cases, a key set that CLOSES at a random step
 (Q2048_FLAG_NO_NEW_ROWS: the oracle agents' `freeze()`; the envs' visit rows cross every launch boundary and every
 switch between the fused rollout and the 4-call API in the row cache).  Boards and aux bit-exact, every Q row within
 rtol 1e-5, the closed key sets exactly the oracle's."""
@@ -68,7 +68,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
                 agent.frozen = True                      # (closed by hand at the oracle's step; the policy has its own tests)
             elif done_steps < freeze_at:
                 k = min(k, freeze_at - done_steps)       # a launch boundary exactly where the key set closes
-        if four_call and rng.integers(0, 2):
+        if four_call and rng.integers(0, 3) == 0:
+            # (lanes with private rows: the two-phase step IS the sequential one; its visit rows use the same records)
+            agent.deterministic_rollout(env, k)
+        elif four_call and rng.integers(0, 2):
             state = env.boards
             for _ in range(k):
                 a = agent.choose_action(state)

@@ -4,7 +4,8 @@
  * (Q2048_HOST_THREADS).  Built and run by tests/sanitize.sh with -fsanitize=thread (and =address,undefined); exits 0
  * when no row is lost (occupied slots == rows created), the deterministic step with 4 threads equals the one with 1
  * thread bit for bit, an export / import round trip returns every row, and a rollout with the key set closed
- * (Q2048_FLAG_NO_NEW_ROWS, visit rows through a row cache) creates none. */
+ * (Q2048_FLAG_NO_NEW_ROWS, visit rows through a row cache) creates none -- fused, then the deterministic step on the
+ * same records (4 threads == 1 thread there too, row cache included). */
 #define _POSIX_C_SOURCE 200809L
 #include <stdint.h>
 #include <stdio.h>
@@ -95,6 +96,30 @@ int main(void) {
                                      Q2048_FLAG_NO_NEW_ROWS, sz, NULL, &st2, &o, NULL));
       CHECK(q2048_fused_rollout_opts(boards, aux, table, CAP, B, n, STEPS / 2, 0.1, 0.1, 0.99, 3, 0, STEPS + STEPS / 2,
                                      Q2048_FLAG_NO_NEW_ROWS | Q2048_FLAG_TD_CAS, sz, NULL, &st2, &o, NULL));
+      /* ... and on into the deterministic step, whose visit rows live in the same records: 4 threads == 1 thread */
+      uint8_t *bd1 = zalloc(B * cells), *bd4 = zalloc(B * cells);
+      q2048_aux *ad1 = zalloc(B * sizeof(q2048_aux)), *ad4 = zalloc(B * sizeof(q2048_aux));
+      void *c1 = zalloc((size_t)B * q2048_sizeof_rowcache(n)), *c4 = zalloc((size_t)B * q2048_sizeof_rowcache(n));
+      int64_t d1[Q2048_NSTAT_I] = {0}, d4[Q2048_NSTAT_I] = {0};
+      memcpy(bd1, boards, B * cells); memcpy(bd4, boards, B * cells);
+      memcpy(ad1, aux, B * sizeof(q2048_aux)); memcpy(ad4, aux, B * sizeof(q2048_aux));
+      memcpy(c1, cache, (size_t)B * q2048_sizeof_rowcache(n)); memcpy(c4, cache, (size_t)B * q2048_sizeof_rowcache(n));
+      /* (both runs on `table` itself, restored in between: a record carries a tag of the table's address) */
+      q2048_slot *keep = zalloc(sizeof(q2048_slot) << CAP), *td1 = zalloc(sizeof(q2048_slot) << CAP);
+      memcpy(keep, table, sizeof(q2048_slot) << CAP);
+      setenv("Q2048_HOST_THREADS", "1", 1);
+      CHECK(q2048_det_rollout_cached(bd1, ad1, table, CAP, B, n, 6, 0.05, 0.1, 0.99, 3, 0, 2 * STEPS, Q2048_FLAG_NO_NEW_ROWS,
+                                     d1, NULL, &st2, w, 256, c1, NULL));
+      memcpy(td1, table, sizeof(q2048_slot) << CAP);
+      memcpy(table, keep, sizeof(q2048_slot) << CAP);
+      setenv("Q2048_HOST_THREADS", "4", 1);
+      CHECK(q2048_det_rollout_cached(bd4, ad4, table, CAP, B, n, 6, 0.05, 0.1, 0.99, 3, 0, 2 * STEPS, Q2048_FLAG_NO_NEW_ROWS,
+                                     d4, NULL, &st2, w, 256, c4, NULL));
+      bad |= memcmp(bd1, bd4, B * cells) != 0 || memcmp(ad1, ad4, B * sizeof(q2048_aux)) != 0 || memcmp(d1, d4, sizeof d1) != 0 ||
+             memcmp(c1, c4, (size_t)B * q2048_sizeof_rowcache(n)) != 0 || memcmp(td1, table, sizeof(q2048_slot) << CAP) != 0 || d1[Q2048_ST_INSERTS] != 0 || d1[Q2048_ST_DROPS] <= 0;
+      free(bd1); free(bd4); free(ad1); free(ad4); free(c1); free(c4); free(td1);
+      memcpy(table, keep, sizeof(q2048_slot) << CAP);
+      free(keep);
       CHECK(q2048_table_count(table, CAP, &after, NULL));
       bad |= after != count || sz[Q2048_ST_INSERTS] != 0 || sz[Q2048_ST_DROPS] <= 0 || sz[Q2048_ST_DROPS] > (int64_t)B * STEPS ||
              sz[Q2048_ST_STEPS] != (int64_t)B * STEPS || (st2 & Q2048_STATUS_TABLE_FULL);

@@ -1520,7 +1520,8 @@ def test_rollout_on_a_full_table_stays_bounded(pkg, n, freeze):
                                                   (4, "four_call", True, 0.3, 50), (5, "four_call", True, 0.3, 50),
                                                   (4, "strict", True, 0.3, 50), (4, "fused", False, 0.3, 50),
                                                   (4, "four_call", False, 0.3, 50), (4, "fused", True, 0.0, 0),
-                                                  (5, "fused", True, 0.02, 8)])
+                                                  (5, "fused", True, 0.02, 8), (4, "mixed", True, 0.3, 50),
+                                                  (5, "mixed", True, 0.0, 0), (4, "det", True, 0.0, 0)])
 def test_closed_key_set_private_rows_match_oracle(pkg, O, n, path, cache, eps, k1):
     """Q2048_FLAG_NO_NEW_ROWS with private rows (every env = one reference agent whose dict stops taking keys after
     k1 steps: the oracle's `freeze()`).  The actions depend on the rows, on absent states reading as the zero row the
@@ -1530,7 +1531,10 @@ def test_closed_key_set_private_rows_match_oracle(pkg, O, n, path, cache, eps, k
     key set within 1e-5, the key set itself unchanged, drops == the oracle's count of updates whose state has no row,
     no TABLE_FULL.  Through the fused kernel (split launches: the visit row crosses the cut in the row cache; also with
     compare-and-swap TD writes) and the 4-call API; `cache` False: no row cache, a visit row ends with the call (the
-    oracle's ENV_NEW_VISITS).  eps = 0 on an EMPTY closed table: pure greedy play on visit rows alone."""
+    oracle's ENV_NEW_VISITS).  eps = 0 on an EMPTY closed table: pure greedy play on visit rows alone.
+    "det": the deterministic step (with private rows the two-phase semantic IS the sequential one); "mixed": fused
+    rollout, deterministic step and 4-call API in turn -- a visit row crosses every one of the boundaries in the row
+    cache, whichever path wrote the record."""
     B, k2, seed, id0, lr, gamma = 96, 250, 23, 7000, 0.1, 0.99
     env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
     agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
@@ -1544,6 +1548,25 @@ def test_closed_key_set_private_rows_match_oracle(pkg, O, n, path, cache, eps, k
         if path == "four_call":
             _unfused_loop(pkg, env, agent, k)
             calls.extend([1] * k)
+        elif path == "det":
+            for part in (k // 3, k - k // 3):
+                if part:
+                    agent.deterministic_rollout(env, part)
+                    calls.append(part)
+        elif path == "mixed":
+            left, turn = k, 0
+            while left > 0:
+                part = min(left, (17, 9, 5, 1, 23, 2)[turn % 6])
+                if turn % 3 == 0:
+                    agent.fused_rollout(env, part)
+                    calls.append(part)
+                elif turn % 3 == 1:
+                    agent.deterministic_rollout(env, part)
+                    calls.append(part)
+                else:
+                    _unfused_loop(pkg, env, agent, part)
+                    calls.extend([1] * part)
+                left, turn = left - part, turn + 1
         else:
             for part in (k // 3, k - k // 3):             # (split launches: the flag travels with each)
                 if part:
@@ -1586,7 +1609,7 @@ def test_closed_key_set_private_rows_match_oracle(pkg, O, n, path, cache, eps, k
           f"worst relative Q error {worst:.2e}, longest streak of one action {int(envs['consecutive_count'].max())}")
     assert drops > 0.2 * B * k2                           # most of a 2048 game's states are new
     assert st["drops"] == drops and st["inserts"] == rows == rows1 == agent.table_size()
-    assert (path == "four_call" or st["steps"] == B * (k1 + k2)) and agent.check_status() == 0
+    assert (path in ("four_call", "mixed") or st["steps"] == B * (k1 + k2)) and agent.check_status() == 0
     if eps == 0.0:        # greedy play on visit rows: an invalid move teaches the next choice -- nobody repeats one action into the stall rule
         assert int(envs["consecutive_count"].max()) <= 60 and st["episodes"] > 0   # (valid repeats of one action happen; 100 invalid ones would end the episode)
     assert pkg._native.claim_timeouts(LIB(pkg)) == 0
@@ -1622,12 +1645,13 @@ def test_closed_key_set_shared_table_drops_match_oracle(pkg, O, n):
     print(f"[closed key set {n}x{n}, shared] {size1} rows, {st['drops']} of {B * k2} updates dropped == the oracle's count")
 
 
-@pytest.mark.parametrize("n", [4, 5])
-def test_closed_key_set_deterministic_mode_is_bit_exact(pkg, O, n):
-    """The deterministic step with Q2048_FLAG_NO_NEW_ROWS on a SHARED table at epsilon 0.2 against the oracle's
-    two-phase semantic with a dict that stopped taking keys (float32 rows): boards bit-exact, the WHOLE table
-    bit-exact, the same drops."""
-    B, k1, k2, seed, id0, eps, lr, gamma = 3000, 30, 90, 41, 10, 0.2, 0.1, 0.95
+@pytest.mark.parametrize("n,eps", [(4, 0.2), (5, 0.2), (4, 0.0)])
+def test_closed_key_set_deterministic_mode_is_bit_exact(pkg, O, n, eps):
+    """The deterministic step with Q2048_FLAG_NO_NEW_ROWS on a SHARED table at epsilon 0.2 (and 0: greedy) against the
+    oracle's two-phase semantic with a dict that stopped taking keys (float32 rows): boards bit-exact, the WHOLE
+    table bit-exact, the same drops.  The envs' visit rows (q2048_det_rollout_cached) cross the call boundary in the
+    row cache; every action of a greedy env in a state without a row depends on them."""
+    B, k1, k2, seed, id0, lr, gamma = 3000, 30, 90, 41, 10, 0.1, 0.95
     env = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
     agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
                                       capacity_log2=20, seed=seed, env_id0=id0, device=DEV, board_size=n,
