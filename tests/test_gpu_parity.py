@@ -2168,6 +2168,24 @@ def test_deterministic_mode_1m_boards_matches_oracle(pkg, O, eps):
     st, vals = check("mid-game")
     assert st["episodes"] > 1000 and len(oa) - rows_before > 4 * B     # mid-game: mostly new states
     assert agent.check_status() == 0
+    if eps == 0.2:
+        # ... and on with the KEY SET CLOSED (Q2048_FLAG_NO_NEW_ROWS, q2048_det_rollout_cached): most mid-game states
+        # have no row, four lanes of five are greedy -- their visit rows decide the actions, and cross a call boundary
+        rows_closed = len(oa)
+        agent.frozen = True
+        oa.freeze()
+        agent.deterministic_rollout(env, 3)
+        agent.deterministic_rollout(env, 3)
+        si3, _ = O.rollout_sync(envs, oa, 6, seed, id0, 272)
+        assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16]), "closed key set"
+        assert_aux(env.aux_fields(), envs, "closed key set")
+        keys, vals = oa.dump()
+        got = agent.q_values(t8(keys)).cpu().numpy()
+        ne = int((got != vals.astype(np.float32)).sum())
+        assert ne == 0, f"closed key set: {ne} of {got.size} Q entries differ in the last bit"
+        st3 = agent.stats()
+        assert st3["inserts"] == agent.table_size() == len(oa) == rows_closed
+        assert st3["drops"] == si3[O.ST_DROPS] == oa.drops > 2 * B and agent.check_status() == 0
     del agent, env
     release_cached_device_memory()
 
