@@ -203,6 +203,8 @@ _SIGNATURES = {
                                            C.c_int64, C.c_double, C.c_double, C.c_double, C.c_uint64,
                                            C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "q2048_rowcache_rebind": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_void_p]),
     "q2048_legal_moves": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "q2048_encode_onehot": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "q2048_rt_choose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_uint64,

@@ -978,6 +978,11 @@ class BatchedQLearningAgent:
             sd["keys"], sd["q"] = self.export_rows()
         else:
             sd["table"] = self.table.to("cpu", copy=True)
+        if self.frozen and self._row_cache is not None:
+            # closed key set: the envs' visit rows are part of the run (a resumed run equals the uninterrupted one
+            # only with them); they live in the row cache, bound to this table's address (q2048_rowcache_rebind)
+            sd["visit_rows"] = {"records": self._row_cache.to("cpu", copy=True), "table_address": int(self.table.data_ptr()),
+                                "capacity_log2": self.capacity_log2}
         return sd
 
     def load_state_dict(self, sd: dict) -> None:
@@ -1000,6 +1005,14 @@ class BatchedQLearningAgent:
         else:
             self.import_rows(sd["keys"], sd["q"])
         self._rebase_rows(self.table_size())
+        v = sd.get("visit_rows")
+        if v is not None and self.row_cache_enabled:
+            # (the key set is the saved one; the launch that follows closes it again -- `_freeze_check` -- before it runs)
+            rec = v["records"]
+            self._row_cache = rec.to(self.device, copy=True).contiguous()
+            N.check(self._L.q2048_rowcache_rebind(_ptr(self._row_cache), rec.shape[0], self.board_size, int(v["table_address"]),
+                                                  int(v["capacity_log2"]), _ptr(self.table), self.capacity_log2,
+                                                  _stream(self.device)), "rowcache_rebind")
 
     def import_rows(self, keys: np.ndarray, q: np.ndarray) -> None:
         """Inserts (key, q[4]) rows exported by `export_rows` (any capacity that holds them)."""

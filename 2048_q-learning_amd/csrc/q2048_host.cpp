@@ -225,6 +225,16 @@ inline void visit_put(void* cache, int64_t i, const q2048_slot* table, u64 mask,
   r.slot = kCacheSlotMask | cache_tag(table, mask);
 }
 
+// q2048_rowcache_rebind: visit rows follow their table's rows into another allocation; every other record is emptied
+template <int N>
+void rowcache_rebind_n(void* row_cache, int64_t B, u64 tag_from, u64 tag_to) {
+  RowCacheRec<N>* c = static_cast<RowCacheRec<N>*>(row_cache);
+  for (int64_t i = 0; i < B; ++i) {
+    if (c[i].key != 0ull && c[i].slot == (kCacheSlotMask | tag_from)) c[i].slot = kCacheSlotMask | tag_to;
+    else std::memset(&c[i], 0, sizeof c[i]);
+  }
+}
+
 // ---- threads ---------------------------------------------------------------------------------------------------
 int threads_for(int64_t B) {
   int T = 0;
@@ -748,6 +758,18 @@ const char* q2048_strerror(int code) {
 size_t q2048_sizeof_aux(void) { return sizeof(q2048_aux); }
 size_t q2048_sizeof_slot(void) { return sizeof(q2048_slot); }
 size_t q2048_sizeof_rowcache(int n) { return n == 4 ? 32 : n == 5 ? 48 : 0; }
+int q2048_rowcache_rebind(void* row_cache, int64_t B, int n, const q2048_slot* from_table, int from_cap_log2,
+                          const q2048_slot* to_table, int to_cap_log2, void*) {
+  if (int e = check_batch(B, n)) return e;
+  if (int e = check_table(from_table, from_cap_log2)) return e;   // (an address of the past: never dereferenced)
+  if (int e = check_table(to_table, to_cap_log2)) return e;
+  if (row_cache == nullptr) return Q2048_ERR_NULL;
+  if (!aligned16(row_cache)) return Q2048_ERR_ALIGN;
+  const u64 tag_from = cache_tag(from_table, (1ull << from_cap_log2) - 1ull), tag_to = cache_tag(to_table, (1ull << to_cap_log2) - 1ull);
+  if (n == 4) rowcache_rebind_n<4>(row_cache, B, tag_from, tag_to);
+  else rowcache_rebind_n<5>(row_cache, B, tag_from, tag_to);
+  return Q2048_OK;
+}
 
 int q2048_env_init(uint8_t* boards, q2048_aux* aux, int64_t B, int n, uint64_t seed, uint64_t env_id0, void*) {
   if (int e = check_batch(B, n)) return e;

@@ -801,7 +801,7 @@ static_assert(sizeof(RowCache<4>) == 32 && sizeof(RowCache<5>) == 48, "ABI layou
 // caller switched tables and did not zero the cache -- never matches, so its slot index is never used against the
 // wrong table (records outlive launches since round 4 and were trusted on a key match alone).  A table
 // rewritten IN PLACE (zero-filled, imported into) keeps its tag: the caller zero-fills the cache then, as before.
-__device__ __forceinline__ u64 cache_tag(const q2048_slot* table, u64 mask) {
+__host__ __device__ __forceinline__ u64 cache_tag(const q2048_slot* table, u64 mask) {
   return (mix64((u64)reinterpret_cast<uintptr_t>(table) ^ (mask * 0x9E3779B97F4A7C15ull)) >> 40) << 40;
 }
 constexpr u64 kCacheSlotMask = (1ull << 40) - 1ull;
@@ -859,6 +859,22 @@ __device__ __forceinline__ void cache_put(RowCache<5>* c, int64_t i, const Geo<5
   p[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), f32_bits(r.q0), f32_bits(r.q1));
   p[1] = make_uint4(f32_bits(r.q2), f32_bits(r.q3), (uint32_t)key.k1, (uint32_t)(key.k1 >> 32));
   p[2] = make_uint4((uint32_t)s, (uint32_t)(s >> 32), 0u, 0u);
+}
+
+// q2048_rowcache_rebind: the visit rows of a cache follow their table's ROWS into another allocation (a checkpoint
+// restored): a record without a slot that carries the old table's tag gets the new table's; every other record (the
+// slot indices of the old allocation mean nothing in the new one) is emptied.
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_rowcache_rebind(RowCache<N>* cache, int64_t B, u64 tag_from, u64 tag_to) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  RowCache<N> r = cache[i];
+  if (r.key != 0ull && r.slot == (kCacheRowless | tag_from)) {
+    r.slot = kCacheRowless | tag_to;
+  } else {
+    r = RowCache<N>{};
+  }
+  cache[i] = r;
 }
 
 template <int N>
@@ -2260,6 +2276,24 @@ int q2048_q_choose_draws(const q2048_slot* table, int cap_log2, const uint8_t* b
 }
 
 size_t q2048_sizeof_rowcache(int n) { return n == 4 ? sizeof(RowCache<4>) : n == 5 ? sizeof(RowCache<5>) : 0; }
+
+int q2048_rowcache_rebind(void* row_cache, int64_t B, int n, const q2048_slot* from_table, int from_cap_log2,
+                          const q2048_slot* to_table, int to_cap_log2, void* stream) {
+  if (int e = check_batch(B, n)) return e;
+  if (int e = check_table(from_table, from_cap_log2)) return e;   // (an address of the past: never dereferenced)
+  if (int e = check_table(to_table, to_cap_log2)) return e;
+  if (row_cache == nullptr) return Q2048_ERR_NULL;
+  if (!aligned16(row_cache)) return Q2048_ERR_ALIGN;
+  if (B == 0) return Q2048_OK;
+  const u64 tag_from = cache_tag(from_table, (1ull << from_cap_log2) - 1ull), tag_to = cache_tag(to_table, (1ull << to_cap_log2) - 1ull);
+  if (n == 4)
+    hipLaunchKernelGGL(k_rowcache_rebind<4>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream,
+                       static_cast<RowCache<4>*>(row_cache), B, tag_from, tag_to);
+  else
+    hipLaunchKernelGGL(k_rowcache_rebind<5>, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream,
+                       static_cast<RowCache<5>*>(row_cache), B, tag_from, tag_to);
+  return launch_status();
+}
 
 int q2048_q_update_cached(q2048_slot* table, int cap_log2, const uint8_t* boards_s, const uint8_t* actions,
                           const float* reward, const uint8_t* boards_s2, const uint8_t* done, int64_t B,

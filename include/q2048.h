@@ -306,6 +306,16 @@ int q2048_q_update(q2048_slot *table, int cap_log2, const uint8_t *boards_s,
  * carries a 24-bit tag of the table's address and capacity, so that records of another table miss instead of steering
  * writes through stale slot indices -- with probability 1 - 2^-24 per pair of tables: a net, not the contract. */
 size_t q2048_sizeof_rowcache(int n);
+/* A cache's VISIT ROWS (Q2048_FLAG_NO_NEW_ROWS) follow their table's rows into another allocation -- a checkpoint of
+ * a learner with a closed key set, restored: the host saves the cache's bytes beside the table's rows, the old
+ * table's address and capacity (two numbers; `from_table` is never dereferenced), restores the rows into `to_table`
+ * (any capacity that holds them) and calls this on the restored bytes.  Every record without a slot that a call on
+ * `from_table` left becomes one of `to_table`; every other record is emptied (a slot index of the old allocation
+ * means nothing in the new one).  The resumed run then equals the uninterrupted one step for step; without it the
+ * envs that were in a state without a row at the checkpoint start that visit again from the zero row.  The two
+ * tables must hold the SAME KEY SET (a visit row stands in for a row that does not exist). */
+int q2048_rowcache_rebind(void *row_cache, int64_t B, int n, const q2048_slot *from_table, int from_cap_log2,
+                          const q2048_slot *to_table, int to_cap_log2, void *stream);
 int q2048_q_choose_cached(const q2048_slot *table, int cap_log2, const uint8_t *boards, int64_t B,
                           int n, double eps, uint64_t seed, uint64_t env_id0, uint32_t ctr,
                           uint32_t flags, const void *row_cache, uint8_t *actions,

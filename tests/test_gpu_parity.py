@@ -238,6 +238,17 @@ def test_abi_argument_errors(pkg):
     assert L.q2048_encode_onehot(b.data_ptr(), (2 ** 31 - 1) * 4 + 1, 0, a.data_ptr(), None) == -2
     with pytest.raises(ValueError):
         pkg.BatchedGame2048Env(4, profile="other", device=DEV)
+    # q2048_rowcache_rebind: arguments first; a record that is no visit row of `from_table` is emptied, not re-bound
+    c = torch.full((4, 32), 0x5A, dtype=torch.uint8, device=DEV)
+    t = torch.zeros(1 << 9, dtype=torch.uint8, device=DEV)            # (stands for two tables of 2^4 slots)
+    assert L.q2048_rowcache_rebind(None, 4, 4, t.data_ptr(), 4, t.data_ptr() + 256, 4, None) == -1
+    assert L.q2048_rowcache_rebind(c.data_ptr(), 4, 4, None, 4, t.data_ptr(), 4, None) == -1
+    assert L.q2048_rowcache_rebind(c.data_ptr(), 4, 4, t.data_ptr(), 3, t.data_ptr(), 4, None) == -2
+    assert L.q2048_rowcache_rebind(c.data_ptr() + 8, 4, 4, t.data_ptr(), 4, t.data_ptr() + 256, 4, None) == -3
+    assert L.q2048_rowcache_rebind(c.data_ptr(), 4, 6, t.data_ptr(), 4, t.data_ptr() + 256, 4, None) == -4
+    assert int(c.min()) == 0x5A
+    assert L.q2048_rowcache_rebind(c.data_ptr(), 4, 4, t.data_ptr(), 4, t.data_ptr() + 256, 4, None) == 0
+    assert int(c.max()) == 0
 
 
 def test_flag_bits_outside_the_abi_are_refused(pkg):
@@ -1710,35 +1721,56 @@ def test_growing_table_freezes_at_its_largest_capacity(pkg):
     assert fresh.frozen and fresh.table_size() == check["rows"]
 
 
-@pytest.mark.parametrize("n", [4, 5])
-def test_checkpoint_resume_is_bit_exact(pkg, n):
+@pytest.mark.parametrize("n,closed", [(4, False), (5, False), (4, True), (5, True)])
+def test_checkpoint_resume_is_bit_exact(pkg, n, closed):
     """state_dict / load_state_dict: stop after 60 steps, reload into fresh
-    objects with a DIFFERENT table capacity, continue 40 steps == the uninterrupted run."""
-    B, seed, id0 = 300, 9, 4242
+    objects with a DIFFERENT table capacity, continue 40 steps == the uninterrupted run.
+    `closed`: the key set closes (Q2048_FLAG_NO_NEW_ROWS) 30 steps before the checkpoint, at epsilon 0.05 -- the
+    envs' VISIT ROWS are part of the run: they travel in the checkpoint (`visit_rows`: the row cache's bytes,
+    re-bound to the restored table by q2048_rowcache_rebind), and a resume without them plays other moves."""
+    B, seed, id0, eps = 300, 9, 4242, (0.05 if closed else 0.3)
 
     def mk(cap):
         e = pkg.BatchedGame2048Env(B, board_size=n, seed=seed, env_id0=id0, device=DEV)
-        a = pkg.BatchedQLearningAgent(100, exploration_rate=0.3, discount_factor=0.95, capacity_log2=cap,
-                                      seed=seed, env_id0=id0, device=DEV, independent=True, board_size=n)
+        a = pkg.BatchedQLearningAgent(100, exploration_rate=eps, discount_factor=0.95, capacity_log2=cap,
+                                      seed=seed, env_id0=id0, device=DEV, independent=True, board_size=n,
+                                      freeze_load=None)
         return e, a
 
-    e1, a1 = mk(17); a1.fused_rollout(e1, 60)
+    e1, a1 = mk(17)
+    if closed:
+        a1.fused_rollout(e1, 30)
+        a1.frozen = True
+        a1.fused_rollout(e1, 30)
+    else:
+        a1.fused_rollout(e1, 60)
     sd_env, sd_agent = e1.state_dict(), a1.state_dict()
+    assert ("visit_rows" in sd_agent) == closed
     a1.decay_exploration(0); eps_after = a1.epsilon
     a1.fused_rollout(e1, 40)
-    e2, a2 = mk(19)
-    e2.load_state_dict(sd_env); a2.load_state_dict(sd_agent)
-    assert a2.table_size() == len(sd_agent["q"]) and (e2.ctr, a2.ctr) == (60, 60)
-    a2.decay_exploration(0); assert a2.epsilon == eps_after
-    a2.fused_rollout(e2, 40)
+
+    def resume(sd):
+        e2, a2 = mk(19)
+        e2.load_state_dict(sd_env); a2.load_state_dict(sd)
+        assert a2.table_size() == len(sd["q"]) and (e2.ctr, a2.ctr) == (60, 60)
+        a2.frozen = closed
+        a2.decay_exploration(0); assert a2.epsilon == eps_after
+        a2.fused_rollout(e2, 40)
+        return e2, a2
+
+    e2, a2 = resume(sd_agent)
     assert torch.equal(e1.boards, e2.boards) and torch.equal(e1.aux, e2.aux)
     k1, q1 = a1.export_rows(); k2, q2 = a2.export_rows()
     k1 = k1.reshape(len(q1), -1); k2 = k2.reshape(len(q2), -1)
     o1 = np.lexsort(k1.T[::-1]); o2 = np.lexsort(k2.T[::-1])
     assert np.array_equal(k1[o1], k2[o2]) and np.array_equal(q1[o1], q2[o2])
     s1, s2 = a1.stats(), a2.stats()
-    for k in ("steps", "episodes", "valid_moves", "score_sum", "explored"):
+    for k in ("steps", "episodes", "valid_moves", "score_sum", "explored", "drops", "inserts"):
         assert s1[k] == s2[k], k
+    if closed:
+        assert s1["drops"] > 0 and s1["inserts"] == len(q1) == len(sd_agent["q"])
+        e3, _ = resume({k: v for k, v in sd_agent.items() if k != "visit_rows"})
+        assert not torch.equal(e1.boards, e3.boards)      # (the test has teeth: the visit rows decide moves)
 
 
 def test_export_dict_is_the_reference_table(pkg, O):

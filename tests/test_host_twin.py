@@ -151,6 +151,34 @@ def test_train_two_ranks_on_the_cpu_device_equal_one_rank(tmp_path):
         assert int(a[8]) == int(b[8]) == 0                       # no drops
 
 
+def test_train_resume_of_a_run_with_a_closed_key_set(tmp_path):
+    """`train.py --save` / `--resume` ACROSS the freeze (SURVEY 8(f) row 1 x 7.3): a 2^14-slot table that cannot grow
+    closes its key set in the first epoch; the run is stopped at epoch 4 and resumed to 8.  In deterministic mode the
+    resumed run's report rows and its final table are the uninterrupted run's, bit for bit -- the envs' visit rows
+    travel in the checkpoint (agent.state_dict()["visit_rows"], q2048_rowcache_rebind) and the restored table closes
+    its key set again before its first launch."""
+    import csv
+    import subprocess
+
+    common = ["--device", "cpu", "--num-envs", "512", "--steps-per-launch", "32", "--report-every", "1", "--capacity-log2", "14",
+              "--deterministic", "--epsilon", "0.9", "--seed", "3", "--episodes", "8"]
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(REPO, "train.py"), *common, *a],   # noqa: E731
+                                    capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    rows = lambda f: [r[:9] for r in list(csv.reader(open(tmp_path / f)))[1:]]   # noqa: E731  (Steps/s left out)
+    pf = run("--save", "full.pt", "--log", "full.csv")
+    assert pf.returncode == 0 and "table frozen at step" in pf.stdout, pf.stderr[-2000:]
+    p1 = run("--stop-epoch", "4", "--save", "part.pt", "--log", "p1.csv")
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    p2 = run("--resume", "part.pt", "--save", "resumed.pt", "--log", "p2.csv")
+    assert p2.returncode == 0 and "table frozen at step" in p2.stdout and "(frozen)" in p2.stdout, p2.stderr[-2000:]
+    full = rows("full.csv")
+    assert rows("p1.csv") + rows("p2.csv") == full and int(full[-1][8]) > 0          # ... drops included
+    a, b, part = (torch.load(tmp_path / f, map_location="cpu", weights_only=False) for f in ("full.pt", "resumed.pt", "part.pt"))
+    assert "visit_rows" in part and len(part["q"]) == len(a["q"]) <= 0.5 * (1 << 14) + 2 * 512 * 32
+    oa, ob = np.argsort(a["keys"]), np.argsort(b["keys"])
+    assert np.array_equal(a["keys"][oa], b["keys"][ob]) and np.array_equal(a["q"][oa], b["q"][ob])
+
+
 def test_eight_ranks_on_the_cpu_device_equal_one_rank(tmp_path):
     """BASELINE configs[3]'s partition at its real world size, without GPUs: EIGHT self-launched ranks (launch.py: eight
     fresh children, a gloo group) on the CPU twin, each owning the global env ids [r B, (r + 1) B) and its own table
