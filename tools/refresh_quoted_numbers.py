@@ -89,7 +89,8 @@ s = sub(s, rf"\| 5×5 boards, 1,048,576 envs \| {NUM}–{NUM}·10¹⁰ env-steps
 s = sub(s, rf"— {NUM} on 64-step ones\)", f"— {c5d['roofline_frac']:.3f} on 64-step ones)", "README 5x5 default")
 s = sub(s, r"\| [0-9 ]+ iterations/s on the GPU", f"| {ads} iterations/s on the GPU", "README adapters")
 s = sub(s, rf"\| {NUM}·10¹⁰ env-steps/s \({NUM} µs per 1 Mi-board step\) \|", f"| {1048576 / fc1 / 1e4:.2f}·10¹⁰ env-steps/s ({fc1:.1f} µs per 1 Mi-board step) |", "README four-call")
-s = sub(s, rf"\({NUM} µs per 1 Mi-board step in six launches\)", f"({det1:.1f} µs per 1 Mi-board step in six launches)", "README det")
+s = sub(s, rf"\| {NUM}·10⁹ env-steps/s \({NUM} µs per 1 Mi-board step in six launches\)",
+        f"| {sci(1048576 / det1 * 1e6)} env-steps/s ({det1:.1f} µs per 1 Mi-board step in six launches)", "README det")
 open(P("README.md"), "w", encoding="utf-8").write(s)
 
 # ---- INTEGRATION.md -----------------------------------------------------------------------------------------------
