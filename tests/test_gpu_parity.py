@@ -2885,8 +2885,11 @@ def test_no_learn_rollout_reads_but_never_writes(pkg, O, n):
 
 
 def test_train_save_then_evaluate_scripts(tmp_path):
-    """`train.py --save` writes the learner, `evaluate.py` plays it greedily without learning and
-    `train.py --resume` continues from it (the README's train / evaluate / models layout)."""
+    """`train.py --save` writes the learner, `evaluate.py` plays it without learning and `train.py --resume`
+    continues from it (the README's train / evaluate / models layout).  evaluate.py's two policies: `legal` (argmax
+    of the stored row over the moves that change the board: every move but a game's last is valid) and `reference`
+    (the lr = 0 agent, argmax over all four actions, Q2048_FLAG_NO_LEARN: a greedy env repeats an invalid argmax
+    until the stall rule ends the episode -- faithful, and a far worse player)."""
     release_cached_device_memory()
     import subprocess
     import sys
@@ -2894,16 +2897,22 @@ def test_train_save_then_evaluate_scripts(tmp_path):
     from conftest import REPO
 
     model = str(tmp_path / "models" / "q.pt")
-    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))  # noqa: E731
+    run = lambda *a: subprocess.run([sys.executable, *a, "--device", DEV], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))  # noqa: E731
     p = run(os.path.join(REPO, "train.py"), "--num-envs", "4096", "--episodes", "3", "--steps-per-launch", "32",
             "--report-every", "4", "--capacity-log2", "24", "--save", model, "--log", str(tmp_path / "t.csv"))
     assert p.returncode == 0 and os.path.exists(model), p.stderr[-2000:]
-    p = run(os.path.join(REPO, "evaluate.py"), "--model", model, "--num-envs", "2048", "--episodes", "2")
-    assert p.returncode == 0, p.stderr[-2000:]
-    rec = json.loads(p.stdout.strip().splitlines()[-1])
-    # (the table comes from a racing shared-table run: its rows differ a little from run to run)
-    assert rec["games"] >= 2 * 2048 and rec["rows"] > 10000 and rec["epsilon"] == 0.0, rec
-    assert rec["best_tile"] >= 16 and rec["env_steps"] > 0, rec
+    recs = {}
+    for policy in ("legal", "reference"):
+        p = run(os.path.join(REPO, "evaluate.py"), "--model", model, "--num-envs", "2048", "--episodes", "2", "--policy", policy)
+        assert p.returncode == 0, p.stderr[-2000:]
+        rec = recs[policy] = json.loads(p.stdout.strip().splitlines()[-1])
+        # (the table comes from a racing shared-table run: its rows differ a little from run to run)
+        assert rec["games"] >= 2 * 2048 and rec["rows"] > 10000 and rec["epsilon"] == 0.0 and rec["policy"] == policy, rec
+        assert rec["best_tile"] >= 16 and rec["env_steps"] > 0, rec
+    legal, ref = recs["legal"], recs["reference"]
+    assert legal["valid_move_frac"] > 0.98 > 0.6 > ref["valid_move_frac"], (legal, ref)
+    assert legal["mean_score"] > 5 * ref["mean_score"] and legal["best_tile"] >= 256, (legal, ref)
+    assert sum(legal["max_tile_hist"].values()) == legal["games"]
     p = run(os.path.join(REPO, "train.py"), "--num-envs", "4096", "--episodes", "1", "--steps-per-launch", "32",
             "--report-every", "4", "--capacity-log2", "24", "--resume", model, "--log", str(tmp_path / "t2.csv"))
     assert p.returncode == 0, p.stderr[-2000:]
