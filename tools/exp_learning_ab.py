@@ -11,6 +11,8 @@ with 4096 envs on one table, epsilon schedule of Agent/main.py:45-57 applied onc
   det        deterministic mode: updates of a step grouped by (state, action), applied in env order
   frozen     the default store mode on a table too small for the run (2^--frozen-capacity-log2 slots): it closes its
              key set at freeze_load (Q2048_FLAG_NO_NEW_ROWS, round 6) and the rest of the run learns on the rows it has
+  det-frozen the same table in deterministic mode: after the freeze the envs' visit rows live in the row cache
+             (q2048_det_rollout_cached)
 One JSON line per (mode, seed): mean return / score and max-tile histogram of the last 10 epochs."""
 import argparse
 import importlib
@@ -38,7 +40,8 @@ if any(m in ("sc1",) for m in args.modes.split(",")):
 dev = torch.device("cuda:0")
 B, E = args.num_envs, args.episodes
 MODES = {"store/64": dict(S=64), "store/1": dict(S=1), "sc1": dict(S=64, bits=0x200),
-         "cas": dict(S=64, strict=True), "det": dict(S=64, det=True), "frozen": dict(S=64, frozen=True)}
+         "cas": dict(S=64, strict=True), "det": dict(S=64, det=True), "frozen": dict(S=64, frozen=True),
+         "det-frozen": dict(S=64, det=True, frozen=True)}
 for mode in args.modes.split(","):
     cfg = MODES[mode]
     for seed in range(args.seeds):
