@@ -110,6 +110,10 @@ def parse_args(argv=None):
     p.add_argument("--gamma", type=float, default=0.99)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--cap-log2", type=int, default=0, help="0 = load <= 0.5 and up to half the free device memory")
+    p.add_argument("--prefill-load", type=float, default=0.0,
+                   help="measurement runs: fill the table, untimed, with this share of rows that are no states before the "
+                        "run (>= the agent's freeze_load 0.5: the key set closes at the first launch -- the frozen "
+                        "companion's workload as the main line, for the counter passes)")
     p.add_argument("--placement", default="auto",
                    type=lambda v: v if v in ("auto", "plain", "chunks") else int(v),
                    help="table allocation (agent.place_table): auto | chunks (2 MiB physical chunks, "
@@ -450,7 +454,8 @@ def run_rank(args):
 
     m = measure(pkg, torch, args, dev, shard, world, eps=args.eps, cap_log2=cap_log2,
                 placement=args.placement, steps=args.steps, warmup=args.warmup,
-                repeats=args.repeats, S=S, reducer=reducer)
+                repeats=args.repeats, S=S, reducer=reducer, prefill_load=args.prefill_load,
+                expect_frozen=args.prefill_load >= FREEZE_LOAD)
     s = summarise(m, shard, args.steps, algo_bytes)
     st = s["median_region"]["stats"]
 
@@ -480,6 +485,8 @@ def run_rank(args):
                     "are 32 B, atomics 64 B (profiles/r02_requests/)"}
         cfg = {"boards": shard.num_envs, "steps_per_launch": S, "cap_log2": cap_log2,
                "board_size": args.board_size, "eps": args.eps, "strict_td": bool(args.strict_td)}
+        if args.prefill_load:
+            cfg["prefill_load"] = args.prefill_load
         per_step, source, other = committed_pmc_traffic(cfg)
         if per_step is not None:
             roofline["traffic"] = per_step * shard.num_envs * (args.steps / s["launches"])
@@ -507,7 +514,7 @@ def run_rank(args):
                    "alpha": args.alpha, "gamma": args.gamma, "seed": args.seed,
                    "td_write": "compare-and-swap" if args.strict_td else "store (last writer wins)",
                    "table_placement": m["placement"], "experiment_bits": args.experiment_bits,
-                   "row_cache": not args.no_row_cache,
+                   "row_cache": not args.no_row_cache, "prefill_load": args.prefill_load, "frozen": m["frozen"],
                    "region_statistics": "host-side mirror written by the launch's last block" if m["mirrored"] else (
                        "all-gather (one collective)" if torch.distributed.is_initialized() else "copy to pinned host memory"),
                    "prep_steps": args.prep_steps, "repeats": args.repeats,

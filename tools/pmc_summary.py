@@ -72,7 +72,8 @@ if bench and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
            "config": {"boards": cfg["boards_per_gpu"], "steps_per_launch": S,
                       "cap_log2": cfg["table_capacity_log2"],
                       "board_size": 4 if "4x4" in cfg["workload"] else 5, "eps": cfg["epsilon"],
-                      "strict_td": cfg["td_write"] != "store (last writer wins)"},
+                      "strict_td": cfg["td_write"] != "store (last writer wins)",
+                      **({"prefill_load": cfg["prefill_load"]} if cfg.get("prefill_load") else {})},
            "source": "rocprofv3 --kernel-trace --pmc, one counter set per pass, on `"
                      + open(os.path.join(root, "command.txt")).read().strip() + "`, timed dispatches only; "
                      "read bytes = " + read_how + ", write bytes = WRITE_SIZE x 1024"}
