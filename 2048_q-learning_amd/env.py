@@ -262,11 +262,18 @@ AUX_DTYPE = np.dtype([("score", "<i4"), ("ep_return", "<f4"), ("prev_max", "u1")
                       ("cons_action", "u1"), ("cons_count", "<u2"), ("episode", "<u4")])
 
 
+_RAW_OF_LOG2 = np.array([0] + [1 << k for k in range(1, 63)] + [0] * 193, dtype=np.int64)   # (one gather; called per step by the adapters)
+
+
 def boards_to_raw(boards_log2) -> np.ndarray:
     """uint8 log2 boards [..., n*n] -> np.int64 raw tile values [..., n, n] (reference layout)."""
-    b = np.asarray(boards_log2, dtype=np.int64)
-    n = int(round(b.shape[-1] ** 0.5))
-    return np.where(b > 0, np.left_shift(1, b), 0).reshape(b.shape[:-1] + (n, n))
+    b = np.asarray(boards_log2)
+    if b.dtype != np.uint8:
+        b = b.astype(np.int64)
+        if b.size and (int(b.min()) < 0 or int(b.max()) > 62):
+            raise ValueError("log2 tiles lie in 0..62")
+    n = 4 if b.shape[-1] == 16 else 5 if b.shape[-1] == 25 else int(round(b.shape[-1] ** 0.5))
+    return _RAW_OF_LOG2[b].reshape(b.shape[:-1] + (n, n))
 
 
 def raw_to_boards(raw) -> np.ndarray:
