@@ -31,7 +31,8 @@ GROW_VERIFY_COUNT = 1
 STATUS_BAD_ACTION, STATUS_TILE_OVERFLOW, STATUS_TABLE_FULL, STATUS_DEEP_ROW = 1, 2, 4, 8
 FLAG_INDEPENDENT, FLAG_SINGLE_ENV, FLAG_TD_CAS = 1, 2, 4
 FLAG_ENV_DQN, FLAG_RESET_SHAPING, FLAG_PLAY_ONLY, FLAG_NO_LEARN, FLAG_NO_NEW_ROWS = 8, 16, 32, 64, 128
-ABI_VERSION = 6
+FLAG_LINE_SUMMARY = 1 << 24
+ABI_VERSION = 7
 ST_STEPS, ST_EPISODES, ST_VALID, ST_SCORE, ST_INSERTS, ST_DROPS, ST_EXPLORE, ST_CAS_RETRY = range(8)
 ST_HIST0, NSTAT_I = 8, 32
 ST_HIST_BINS, ST_CAS_FALLBACK = 23, 31
@@ -194,6 +195,7 @@ _SIGNATURES = {
     "q2048_table_free": (C.c_int, [C.c_void_p]),
     "q2048_table_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_void_p]),
     "q2048_table_count": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "q2048_table_summarise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "q2048_det_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "q2048_det_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                     C.c_int64, C.c_double, C.c_double, C.c_double, C.c_uint64,

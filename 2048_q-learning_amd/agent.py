@@ -387,6 +387,9 @@ class BatchedQLearningAgent:
             raise ValueError("freeze_load must be in [0.05, 0.95], or None (never freeze)")
         self.freeze_load = None if freeze_load is None else float(freeze_load)
         self.frozen, self.frozen_at = False, None  # the key set is closed (Q2048_FLAG_NO_NEW_ROWS on every launch)
+        # a 4x4 table with a closed key set carries LINE SUMMARIES (q2048_table_summarise, Q2048_FLAG_LINE_SUMMARY): one
+        # request per lookup of an absent state instead of 2.35 -- written by the first launch after the key set closed
+        self.line_summaries, self._summarised = True, False
         if self.growable:
             if not 0.05 <= self.load_limit <= 0.9:
                 raise ValueError("load_limit must be in [0.05, 0.9]")
@@ -640,13 +643,23 @@ class BatchedQLearningAgent:
         return self._rows_base + seen - self._inserts_at_base
 
     def _learn_flags(self) -> int:
-        """The agent's flags for a call that may create rows: with the key set closed, Q2048_FLAG_NO_NEW_ROWS."""
-        return self.flags | (N.FLAG_NO_NEW_ROWS if self.frozen else 0)
+        """The agent's flags for a call that may create rows: with the key set closed, Q2048_FLAG_NO_NEW_ROWS -- and,
+        on a 4x4 table, Q2048_FLAG_LINE_SUMMARY once the summaries of THIS key set are written (one streaming pass,
+        queued ahead of the first launch that uses them; a call that may create rows ends their validity)."""
+        if not self.frozen:
+            self._summarised = False
+            return self.flags
+        if self.board_size == 4 and self.line_summaries and not self._summarised:
+            N.check(self._L.q2048_table_summarise(_ptr(self.table), self.capacity_log2, _stream(self.device)),
+                    "table_summarise")
+            self._summarised = True
+        return self.flags | N.FLAG_NO_NEW_ROWS | (N.FLAG_LINE_SUMMARY if self._summarised and self.line_summaries else 0)
 
     def _rebase_rows(self, rows: int, table_changed: bool = True) -> None:
         """`rows` rows are in the table now (a count, an import): the new base of the row bookkeeping."""
         if table_changed:
             self.frozen = False                           # (decided again by the next `_room_for`)
+            self._summarised = False                      # (line summaries describe a key set that is gone)
         self._rows_base = int(rows)
         self._inserts_at_base = self._inserts_seen = self._cumulative_inserts()
         self._steps_at_read, self._steps_unseen = self._steps_launched, 0

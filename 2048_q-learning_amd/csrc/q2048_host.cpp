@@ -293,7 +293,8 @@ inline int check_table(const void* table, int cap_log2) {
 }
 constexpr uint32_t kAbiFlags = Q2048_FLAG_INDEPENDENT | Q2048_FLAG_SINGLE_ENV | Q2048_FLAG_TD_CAS | Q2048_FLAG_ENV_DQN |
                                Q2048_FLAG_RESET_SHAPING | Q2048_FLAG_PLAY_ONLY | Q2048_FLAG_NO_LEARN |
-                               Q2048_FLAG_NO_NEW_ROWS;
+                               Q2048_FLAG_NO_NEW_ROWS | Q2048_FLAG_LINE_SUMMARY;   // (the last one: accepted, not used --
+                                                                                   // this library probes slot by slot; same results)
 inline int check_flags(uint32_t flags, uint32_t refused = 0u) {
   return ((flags & ~kAbiFlags) || (flags & refused)) ? Q2048_ERR_FLAGS : Q2048_OK;
 }
@@ -1001,6 +1002,22 @@ int q2048_table_export(const q2048_slot* table, int cap_log2, uint64_t* keys_out
     ++at;
   }
   *count = at;
+  return Q2048_OK;
+}
+// the device's line summaries, byte for byte (q2048_kernels.hip: summary_fp, k_table_summarise): four 16-bit
+// fingerprints per 128-byte line, 0 = empty, the same word in the `reserved` field of the line's four slots
+int q2048_table_summarise(q2048_slot* table, int cap_log2, void*) {
+  if (int e = check_table(table, cap_log2)) return e;
+  const int64_t lines = (int64_t)((1ull << cap_log2) >> 2);
+  parallel_ranges(lines, [=](int64_t lo, int64_t hi, int) {
+    for (int64_t l = lo; l < hi; ++l) {
+      q2048_slot* s = table + (l << 2);
+      u64 sum = 0ull;
+      for (int r = 0; r < 4; ++r)
+        if (s[r].key != 0ull) sum |= (((mix64(s[r].key) >> 48) & 0xffffull) | 1ull) << (16 * r);
+      for (int r = 0; r < 4; ++r) s[r].reserved = sum;
+    }
+  });
   return Q2048_OK;
 }
 int q2048_table_count(const q2048_slot* table, int cap_log2, int64_t* count, void* stream) {

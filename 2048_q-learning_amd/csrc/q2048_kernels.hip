@@ -349,6 +349,77 @@ __device__ __forceinline__ int64_t probe_find(const q2048_slot* table, u64 mask,
   return kNoSlot;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LINE SUMMARIES (4x4 tables with a closed key set: Q2048_FLAG_LINE_SUMMARY after q2048_table_summarise).
+// What a lookup costs is the number of requests its lane sends to the L2, hits included: on a table at load 0.5 the
+// slot-by-slot probe of an ABSENT state -- most lookups of a run that has outgrown its table -- sends 2.35 (one miss,
+// then the line's next slots until one is empty) and the step takes 47.9 us; with ONE request per lookup it takes
+// 27.1 (profiles/r06_one_request.jsonl: the arithmetic alone is 20.9).  A 4x4 slot has 8 bytes to spare (`reserved`:
+// the second key word of 5x5).  Once the key set is closed they can hold what the probe wants to know about the whole
+// LINE: four 16-bit fingerprints, one per slot of the 128-byte line (0 = empty), the same word in all four slots.  The
+// probe then reads the second half of the slot its sequence enters the line at -- {q2, q3, summary}: one request --
+// and knows where the sequence ends: at the first slot, in its order, that is empty (absent: done) or carries the
+// key's fingerprint (one more request, that slot's head, settles it; a false match, 2^-15 per occupied slot, costs
+// that request and nothing else).  Written by one streaming pass when the key set closes; meaningless as soon as a row
+// is created (the caller's contract, include/q2048.h).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ u64 summary_fp(u64 hash) { return ((hash >> 48) & 0xffffull) | 1ull; }   // never 0
+__global__ __launch_bounds__(kBlock) void k_table_summarise(q2048_slot* table, u64 lines) {
+  for (u64 l = (u64)blockIdx.x * kBlock + threadIdx.x; l < lines; l += (u64)gridDim.x * kBlock) {
+    q2048_slot* s = table + (l << 2);
+    u64 sum = 0ull;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u64 k = s[r].key;
+      if (k != 0ull) sum |= summary_fp(mix64(k)) << (16 * r);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r].reserved = sum;
+  }
+}
+__device__ __forceinline__ int64_t probe_find_summary(const q2048_slot* table, u64 mask, const Geo<4>::Key& key,
+                                                      Row& row, bool& created, uint32_t maxp = kRolloutProbe) {
+  const u64 hash = key_hash(key);
+  const Seq sq = seq_of(hash, mask);
+  const u64 fp = summary_fp(hash);
+  created = false;
+  row = Row{0.f, 0.f, 0.f, 0.f};
+  for (uint32_t p = 0, lim = probe_limit(mask, maxp); p < lim; p += 4u) {
+    const u64 base = ((sq.line0 + (u64)(p >> 2)) & sq.lmask) << 2;
+    const u32x4 v = ld16_agent(&table[base | (u64)sq.off].q[2]);          // {q2, q3, summary} of the slot the sequence enters at
+    const u64 sum = (u64)v.z | ((u64)v.w << 32);
+    // bit r: slot r of the line is empty / carries the key's fingerprint
+    uint32_t e = 0u, m = 0u;
+#pragma unroll
+    for (uint32_t r = 0; r < 4u; ++r) {
+      const u64 f = (sum >> (16u * r)) & 0xffffull;
+      e |= (uint32_t)(f == 0ull) << r;
+      m |= (uint32_t)(f == fp) << r;
+    }
+    // the line's slots in the sequence's order (it enters at `off`): position j <-> slot (off + j) & 3
+    uint32_t ev = (((e | m) | ((e | m) << 4)) >> sq.off) & 15u;
+    while (ev != 0u) {
+      const uint32_t j = (uint32_t)__builtin_ctz(ev), r = (sq.off + j) & 3u;
+      const u64 i = base | (u64)r;
+      if ((e >> r) & 1u) return ~(int64_t)i;                                // the sequence ends here: absent
+      const u32x4 h = ld16_agent(&table[i]);                                // a candidate: its head settles it
+      if (((u64)h.x | ((u64)h.y << 32)) == key.k0) {
+        u64 hi = (u64)v.x | ((u64)v.y << 32);
+        if (j != 0u) hi = ld_u64(&table[i].q[2]);
+        row = Row{bits_f32(h.z), bits_f32(h.w), bits_f32((uint32_t)hi), bits_f32((uint32_t)(hi >> 32))};
+        return (int64_t)i;
+      }
+      ev &= ev - 1u;                                                        // another key with this fingerprint
+    }
+  }
+  return kNoSlot;
+}
+template <bool SUMMARY, class Key>
+__device__ __forceinline__ int64_t probe_find_as(const q2048_slot* table, u64 mask, const Key& key, Row& row, bool& created) {
+  if constexpr (SUMMARY && sizeof(Key) == sizeof(u64)) return probe_find_summary(table, mask, key, row, created);
+  else return probe_find(table, mask, key, row, created);
+}
+
 // Find-or-create starting at slot `start` of the key's sequence (the hint of a failed probe_find,
 // or the home slot).  The first access is the claiming compare-and-swap itself: the slot was empty
 // a moment ago.  Returns the slot index or kNoSlot (probe limit: the caller drops the update).
@@ -1039,7 +1110,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_q_update(q2048_slot* table, u6
 // kModeFrozen (a bit, with kModeLearn or kModeCas): Q2048_FLAG_NO_NEW_ROWS -- the key set is closed: no claim is ever
 // issued (the Claim pipeline, the insert of an episode's opening state and of a terminal state compile away), a
 // state without a row reads as zeros and its update is dropped and counted.
-constexpr int kModeLearn = 0, kModeCas = 1, kModeEval = 2, kModeFrozen = 4;
+constexpr int kModeLearn = 0, kModeCas = 1, kModeEval = 2, kModeFrozen = 4, kModeSummary = 8;   // (kModeSummary: with kModeFrozen, 4x4)
 // Lanes per workgroup of the fused rollout: 512 for batches that fill the chip more than twice over at that
 // size (>= 786 432 boards), 256 below.  Nine alternating pairs of the driver's command at 1 Mi boards: 47.2 us
 // per step against 48.3 (8 of 9 pairs; 5x5: 64.4 against 66.4; profiles/r04_block512_*.txt) -- half as many
@@ -1087,6 +1158,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     constexpr bool play_only = (ENV & kEnvPlayOnly) != 0;
     constexpr bool no_learn = MODE == kModeEval;
     constexpr bool frozen = (MODE & kModeFrozen) != 0;
+    constexpr bool summary = (MODE & kModeSummary) != 0 && N == 4;   // line summaries: Q2048_FLAG_LINE_SUMMARY
 #ifdef Q2048_EXPERIMENTS   // bits 8..11 write mode, 12 no row creation, 13 no next-state probe, 14 no deferral, 16..23 CAS attempts
     const uint32_t td_mode = no_learn ? (uint32_t)kTdNone : td_mode_of(flags);
     const bool x_noclaim = ((flags >> 12) & 1u) || play_only || no_learn || frozen, x_noprobe = ((flags >> 13) & 1u) || play_only;
@@ -1107,7 +1179,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
     // scattered 128-byte request per lane: 21.5 us of every launch at 1 Mi boards)
     int64_t slot_s = kNoSlot;
     if (!play_only && (cache == nullptr || !cache_get(cache, i, key_s, cache_tag(table, mask), q, slot_s, frozen)))
-      slot_s = probe_find(table, mask, key_s, q, made0);
+      slot_s = probe_find_as<summary>(table, mask, key_s, q, made0);
     Claim claim{0ull, 0ull, false};
     // wave-uniform counters (ballots) and rare per-lane ones
     uint32_t n_valid = 0, n_explore = 0, n_done = 0, n_insert = wave_count(made0), n_drop = 0;
@@ -1134,7 +1206,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
       int64_t slot_n = slot_s;
       if (!same) {
         if (x_noprobe) { qn = Row{0.f, 0.f, 0.f, 0.f}; slot_n = ~(int64_t)key_home(key_n, mask); }
-        else slot_n = probe_find(table, mask, key_n, qn, ins_n);
+        else slot_n = probe_find_as<summary>(table, mask, key_n, qn, ins_n);
       }
       const float max_next = max4(qn.q0, qn.q1, qn.q2, qn.q3);
       float nq = 0.f;
@@ -1175,7 +1247,7 @@ __global__ __launch_bounds__(BLOCK, Q2048_FUSED_WAVES(N)) void k_fused_rollout(
         key_s = state_key(b, salt, status);
         bool made = false;
         q = Row{0.f, 0.f, 0.f, 0.f};
-        slot_s = play_only ? kNoSlot : probe_find(table, mask, key_s, q, made);
+        slot_s = play_only ? kNoSlot : probe_find_as<summary>(table, mask, key_s, q, made);
         ins_n = ins_n || made;
       } else if (same) {            // invalid move: same state, its row just changed (:100)
         if ((updated || frozen) && !no_learn) row_set(q, act, nq);   // (evaluation: the stored row stays as it is)
@@ -2037,7 +2109,7 @@ inline int check_table(const void* table, int cap_log2) {
   hipLaunchKernelGGL((k_fused_rollout<NN, E, M, BLK>), dim3((unsigned)(((B) + (BLK) - 1) / (BLK))), dim3(BLK), 0, \
                      (hipStream_t)(stream), __VA_ARGS__)
 #define Q2048_LAUNCH_FUSED_CASE(E, M, n, B, stream, ...)                                          \
-  case (E) * 8 + (M):                                                                             \
+  case (E) * 16 + (M):                                                                            \
     if ((n) == 4) {                                                                               \
       if ((B) >= kFusedBigBatch) Q2048_LAUNCH_FUSED_ONE(4, E, M, kFusedBlockBig, B, stream, __VA_ARGS__);     \
       else Q2048_LAUNCH_FUSED_ONE(4, E, M, kFusedBlockSmall, B, stream, __VA_ARGS__);             \
@@ -2046,14 +2118,21 @@ inline int check_table(const void* table, int cap_log2) {
       else Q2048_LAUNCH_FUSED_ONE(5, E, M, kFusedBlockSmall, B, stream, __VA_ARGS__);             \
     }                                                                                             \
     break;
+#define Q2048_LAUNCH_FUSED_CASE4(E, M, B, stream, ...)   /* 4x4 only (fused_mode never asks for it on 5x5) */ \
+  case (E) * 16 + (M):                                                                            \
+    if ((B) >= kFusedBigBatch) Q2048_LAUNCH_FUSED_ONE(4, E, M, kFusedBlockBig, B, stream, __VA_ARGS__);       \
+    else Q2048_LAUNCH_FUSED_ONE(4, E, M, kFusedBlockSmall, B, stream, __VA_ARGS__);               \
+    break;
 #define Q2048_LAUNCH_FUSED_ENV(E, n, B, stream, ...)                                              \
   Q2048_LAUNCH_FUSED_CASE(E, kModeLearn, n, B, stream, __VA_ARGS__)                               \
   Q2048_LAUNCH_FUSED_CASE(E, kModeCas, n, B, stream, __VA_ARGS__)                                 \
   Q2048_LAUNCH_FUSED_CASE(E, kModeEval, n, B, stream, __VA_ARGS__)                                \
   Q2048_LAUNCH_FUSED_CASE(E, kModeFrozen, n, B, stream, __VA_ARGS__)                              \
-  Q2048_LAUNCH_FUSED_CASE(E, kModeFrozen + kModeCas, n, B, stream, __VA_ARGS__)
+  Q2048_LAUNCH_FUSED_CASE(E, kModeFrozen + kModeCas, n, B, stream, __VA_ARGS__)                   \
+  Q2048_LAUNCH_FUSED_CASE4(E, kModeFrozen + kModeSummary, B, stream, __VA_ARGS__)                 \
+  Q2048_LAUNCH_FUSED_CASE4(E, kModeFrozen + kModeSummary + kModeCas, B, stream, __VA_ARGS__)
 #define Q2048_LAUNCH_FUSED(flags, n, B, stream, ...)                                              \
-  switch (env_bits(flags) * 8 + fused_mode(flags)) {                                              \
+  switch (env_bits(flags) * 16 + fused_mode(flags, n)) {                                          \
     Q2048_LAUNCH_FUSED_ENV(0, n, B, stream, __VA_ARGS__)                                          \
     Q2048_LAUNCH_FUSED_ENV(1, n, B, stream, __VA_ARGS__)                                          \
     Q2048_LAUNCH_FUSED_ENV(2, n, B, stream, __VA_ARGS__)                                          \
@@ -2067,15 +2146,17 @@ inline int env_bits(uint32_t flags) {
   return ((flags & Q2048_FLAG_ENV_DQN) ? kEnvDqn : 0) | ((flags & Q2048_FLAG_RESET_SHAPING) ? kEnvResetShaping : 0) |
          ((flags & Q2048_FLAG_PLAY_ONLY) ? kEnvPlayOnly : 0);
 }
-inline int fused_mode(uint32_t flags) {   // play-only launches touch no table: one instantiation
+inline int fused_mode(uint32_t flags, int n) {   // play-only launches touch no table: one instantiation
   if (flags & Q2048_FLAG_PLAY_ONLY) return kModeLearn;
   if (flags & Q2048_FLAG_NO_LEARN) return kModeEval;   // (evaluation creates nothing anyway)
-  return ((flags & Q2048_FLAG_TD_CAS) ? kModeCas : kModeLearn) | ((flags & Q2048_FLAG_NO_NEW_ROWS) ? kModeFrozen : 0);
+  const bool frozen = (flags & Q2048_FLAG_NO_NEW_ROWS) != 0u;
+  return ((flags & Q2048_FLAG_TD_CAS) ? kModeCas : kModeLearn) | (frozen ? kModeFrozen : 0) |
+         ((frozen && n == 4 && (flags & Q2048_FLAG_LINE_SUMMARY)) ? kModeSummary : 0);
 }
 // flag bits outside the ABI are an argument error (experiment builds also take bits 8..23)
 constexpr uint32_t kAbiFlags = Q2048_FLAG_INDEPENDENT | Q2048_FLAG_SINGLE_ENV | Q2048_FLAG_TD_CAS |
                                Q2048_FLAG_ENV_DQN | Q2048_FLAG_RESET_SHAPING | Q2048_FLAG_PLAY_ONLY |
-                               Q2048_FLAG_NO_LEARN | Q2048_FLAG_NO_NEW_ROWS;
+                               Q2048_FLAG_NO_LEARN | Q2048_FLAG_NO_NEW_ROWS | Q2048_FLAG_LINE_SUMMARY;
 inline int check_flags(uint32_t flags, uint32_t refused = 0u) {
   uint32_t allowed = kAbiFlags;
 #ifdef Q2048_EXPERIMENTS
@@ -3261,6 +3342,15 @@ int q2048_table_free(q2048_slot* table) {
     }
   }
   return rc;
+}
+
+int q2048_table_summarise(q2048_slot* table, int cap_log2, void* stream) {
+  if (int e = check_table(table, cap_log2)) return e;
+  const u64 lines = (1ull << cap_log2) >> 2;
+  const u64 blocks = (lines + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_table_summarise, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0,
+                     (hipStream_t)stream, table, lines);
+  return launch_status();
 }
 
 int q2048_table_count(const q2048_slot* table, int cap_log2, int64_t* count, void* stream) {

@@ -49,13 +49,15 @@
 extern "C" {
 #endif
 
-#define Q2048_ABI_VERSION 6 /* 3: flag bits outside the ABI are refused (Q2048_ERR_FLAGS), Q2048_ST_CAS_FALLBACK,
+#define Q2048_ABI_VERSION 7 /* 3: flag bits outside the ABI are refused (Q2048_ERR_FLAGS), Q2048_ST_CAS_FALLBACK,
                                deterministic step sorted by a hash of (state, action)
                                4: q2048_fused_rollout_opts (row cache + statistics mirror of the fused
                                rollout), q2048_table_grow, q2048_table_alloc verifies its zero fill
                                5: growth off the caller's critical path (q2048_table_grow_begin / _poll /
                                _commit / _finish / _abort)
-                               6: Q2048_FLAG_NO_NEW_ROWS (a table that has stopped taking new rows) */
+                               6: Q2048_FLAG_NO_NEW_ROWS (a table that has stopped taking new rows)
+                               7: Q2048_FLAG_LINE_SUMMARY + q2048_table_summarise, q2048_det_rollout_cached,
+                               q2048_rowcache_rebind */
 
 /* return codes */
 #define Q2048_OK 0
@@ -146,6 +148,26 @@ extern "C" {
                                      the cache (q_choose, lookup, env, NO_LEARN, PLAY_ONLY).
                                      The host decides when: BatchedQLearningAgent(freeze_load=0.5) sets it on every
                                      launch once a table at its largest capacity holds that share of rows */
+
+#define Q2048_FLAG_LINE_SUMMARY (1u << 24) /* with Q2048_FLAG_NO_NEW_ROWS, 4x4 tables: the table carries LINE SUMMARIES
+                                     (q2048_table_summarise ran after its last row was created) and the fused rollout
+                                     may decide a lookup from them.  A 4x4 slot has 8 spare bytes (`reserved`: the second
+                                     key word of 5x5); a summary is four 16-bit fingerprints, one per slot of the
+                                     128-byte line (0 = empty), the same word in all four slots.  The lookup reads the
+                                     second half of the first slot of its sequence -- {q2, q3, summary}: ONE request --
+                                     and knows where the sequence ends: at the first slot, in its order, that is empty
+                                     (absent: done) or carries the key's fingerprint (that slot's head, one more
+                                     request, settles it).  The slot-by-slot probe sends 2.35 requests per lookup on a
+                                     table at load 0.5 and the step takes 47.9 us per 2^20 boards; with summaries
+                                     1.1-1.5 and 27-33 us.  Same results, request for request fewer.
+                                     CONTRACT: the summaries describe the key set as it was when q2048_table_summarise
+                                     ran.  Creating a row afterwards (any call without Q2048_FLAG_NO_NEW_ROWS, an import)
+                                     makes them stale, and a stale summary HIDES rows: summarise again before the flag is
+                                     passed again.  Ignored by every entry point but q2048_fused_rollout*, and there for
+                                     5x5 tables, evaluation and play-only launches (they probe slot by slot; the extra
+                                     word never disturbs them: 4x4 lookups, export with key_words 1, count, import and the
+                                     growth's move neither read nor write it).
+                                     (bits 8..23 belong to the measurement build's experiment switches) */
 
 /* per-env state, Game2048_env.__init__ (Game2048_env.py:81-95) + episode bookkeeping */
 typedef struct q2048_aux {
@@ -549,6 +571,12 @@ int q2048_table_free(q2048_slot *table);
  * depends on where in device memory a table lies; reads do not). */
 int q2048_table_probe(q2048_slot *table, int cap_log2, int64_t lanes, int steps, uint64_t seed,
                       void *stream);
+
+/* Writes the LINE SUMMARIES of a 4x4 table whose key set is closed (Q2048_FLAG_LINE_SUMMARY above): one streaming pass
+ * over the table (reads every key, writes every slot's `reserved` word; ~40 ms per 32 GiB), stream-ordered.  Run it
+ * after the last row was created and before the first launch that carries the flag; run it again if rows were created
+ * since.  Never on a 5x5 table (its `reserved` words are key words). */
+int q2048_table_summarise(q2048_slot *table, int cap_log2, void *stream);
 
 /* len(agent.q_table): adds the number of occupied slots to *count (device int64). */
 int q2048_table_count(const q2048_slot *table, int cap_log2, int64_t *count, void *stream);

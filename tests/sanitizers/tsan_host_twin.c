@@ -94,8 +94,10 @@ int main(void) {
       uint32_t st2 = 0;
       CHECK(q2048_fused_rollout_opts(boards, aux, table, CAP, B, n, STEPS / 2, 0.1, 0.1, 0.99, 3, 0, STEPS,
                                      Q2048_FLAG_NO_NEW_ROWS, sz, NULL, &st2, &o, NULL));
+      if (n == 4) CHECK(q2048_table_summarise(table, CAP, NULL));   /* line summaries: written by 4 threads, then passed */
       CHECK(q2048_fused_rollout_opts(boards, aux, table, CAP, B, n, STEPS / 2, 0.1, 0.1, 0.99, 3, 0, STEPS + STEPS / 2,
-                                     Q2048_FLAG_NO_NEW_ROWS | Q2048_FLAG_TD_CAS, sz, NULL, &st2, &o, NULL));
+                                     Q2048_FLAG_NO_NEW_ROWS | Q2048_FLAG_TD_CAS | (n == 4 ? Q2048_FLAG_LINE_SUMMARY : 0u),
+                                     sz, NULL, &st2, &o, NULL));
       /* ... and on into the deterministic step, whose visit rows live in the same records: 4 threads == 1 thread */
       uint8_t *bd1 = zalloc(B * cells), *bd4 = zalloc(B * cells);
       q2048_aux *ad1 = zalloc(B * sizeof(q2048_aux)), *ad4 = zalloc(B * sizeof(q2048_aux));

@@ -1688,6 +1688,103 @@ def test_closed_key_set_deterministic_mode_is_bit_exact(pkg, O, n, eps):
     assert agent.check_status() == 0
 
 
+def test_line_summaries_of_a_closed_key_set(pkg, O):
+    """Q2048_FLAG_LINE_SUMMARY (4x4): q2048_table_summarise writes, into the spare word of every slot, the four 16-bit
+    fingerprints of its 128-byte line (0 = empty; bits 48..63 of the key's hash, | 1) -- checked here word by word
+    against the raw table -- and the fused rollout decides its lookups from them.  Same results as the slot-by-slot
+    probe: with private rows the run with summaries equals the oracle's agents board for board, row for row, drop for
+    drop (`line_summaries = False` is the slot-by-slot probe on the same path).  The agent writes them at the first launch after the key set closed and again after anything that may have
+    created rows (a launch with the key set open); a 5x5 table never gets them (its second word is a key word)."""
+    B, k1, k2, seed, id0, eps, lr, gamma = 192, 60, 120, 5, 900, 0.1, 0.1, 0.95
+    m64 = (1 << 64) - 1
+
+    def mix64(x):                                   # q2048::mix64 (csrc/q2048_core.hpp), restated for the check
+        x = (x * 0x9E3779B97F4A7C15) & m64
+        x ^= x >> 29
+        x = (x * 0xBF58476D1CE4E5B9) & m64
+        x ^= x >> 32
+        return x
+
+    def check_summaries(agent):
+        raw = agent.table.cpu().numpy().view(np.uint64).reshape(-1, 4, 4)      # [line, slot, word]
+        keys, words = raw[:, :, 0], raw[:, :, 3]
+        occupied = np.nonzero(keys.any(axis=1))[0]
+        assert (words[keys.any(axis=1) == False] == 0).all()                   # noqa: E712  (an empty line: summary 0)
+        for line in occupied[:: max(1, len(occupied) // 400)]:
+            want = 0
+            for r in range(4):
+                k = int(keys[line, r])
+                if k:
+                    want |= (((mix64(k) >> 48) & 0xFFFF) | 1) << (16 * r)
+            assert all(int(w) == want for w in words[line]), (line, want, words[line])
+        return len(occupied)
+
+    runs = {}
+    for summaries in (True, False):
+        env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+        agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                          capacity_log2=15, seed=seed, env_id0=id0, device=DEV, freeze_load=None)
+        agent.line_summaries = summaries
+        agent.fused_rollout(env, k1)
+        assert not agent._summarised and not agent.table.cpu().numpy().view(np.uint64).reshape(-1, 4)[:, 3].any()
+        agent.frozen = True
+        agent.fused_rollout(env, k2 // 2)
+        assert agent._summarised == summaries
+        if summaries:
+            assert check_summaries(agent) > 1000
+            # the key set opens again (by hand): rows are created, the summaries are stale -- and are written again
+            # before the next launch that uses them
+            agent.frozen = False
+            agent.fused_rollout(env, 4)
+            assert not agent._summarised
+            agent.frozen = True
+            agent.fused_rollout(env, k2 - k2 // 2 - 4)
+            assert agent._summarised
+            check_summaries(agent)
+        else:
+            agent.frozen = False
+            agent.fused_rollout(env, 4)
+            agent.frozen = True
+            agent.fused_rollout(env, k2 - k2 // 2 - 4)
+        runs[summaries] = agent.stats()
+        assert agent.check_status() == 0 and runs[summaries]["steps"] == B * (k1 + k2)
+    assert runs[True]["drops"] > 0 and runs[False]["drops"] > 0
+    # private rows: the summaries' run against the oracle, value for value
+    env = pkg.BatchedGame2048Env(B, seed=seed, env_id0=id0, device=DEV)
+    agent = pkg.BatchedQLearningAgent(100, learning_rate=lr, discount_factor=gamma, exploration_rate=eps,
+                                      capacity_log2=17, seed=seed, env_id0=id0, device=DEV, independent=True,
+                                      freeze_load=None)
+    agent.fused_rollout(env, k1)
+    agent.frozen = True
+    agent.fused_rollout(env, k2 // 3)
+    agent.fused_rollout(env, k2 - k2 // 3)
+    assert agent._summarised
+    envs = O.envs_init(B, 4, seed, id0)
+    drops = 0
+    for i in range(B):
+        oa = O.Agent(100, 4, lr, gamma, eps)
+        O.rollout(envs[i:i + 1], oa, k1, seed, id0 + i, 0)
+        oa.freeze()
+        O.rollout(envs[i:i + 1], oa, k2, seed, id0 + i, k1)
+        drops += oa.drops
+        keys, vals = oa.dump()
+        got, found = agent.q_values(t8(keys), env_id=id0 + i, return_found=True)
+        assert bool(found.all()) and np.allclose(got.cpu().numpy(), vals, rtol=1e-5, atol=1e-6), i
+    assert np.array_equal(env.boards.cpu().numpy(), envs["board"][:, :16]) and agent.stats()["drops"] == drops > 0
+    # 5x5: the flag is ignored, the second word stays a key word
+    env5 = pkg.BatchedGame2048Env(64, board_size=5, seed=seed, device=DEV)
+    a5 = pkg.BatchedQLearningAgent(100, exploration_rate=0.3, capacity_log2=14, seed=seed, device=DEV, board_size=5,
+                                   freeze_load=None)
+    a5.fused_rollout(env5, 40)
+    before = a5.table.clone()
+    a5.frozen = True
+    a5.experiment_bits = pkg._native.FLAG_LINE_SUMMARY          # (passed by hand: the agent itself never does on 5x5)
+    a5.fused_rollout(env5, 40)
+    assert not a5._summarised and a5.check_status() == 0
+    w0, w1 = (t.cpu().numpy().view(np.uint64).reshape(-1, 4) for t in (before, a5.table))
+    assert np.array_equal(w0[:, 0], w1[:, 0]) and np.array_equal(w0[:, 3], w1[:, 3])     # keys and second words untouched
+
+
 def test_growing_table_freezes_at_its_largest_capacity(pkg):
     """capacity_log2="auto" with max_capacity_log2 = 2^20: the table grows 2^16 -> 2^18 -> 2^20 like the defaultdict
     (every growth checks rows moved == rows created), then -- it cannot grow any more -- closes its key set at

@@ -30,7 +30,7 @@ def test_abi_exports_every_declared_symbol(pkg):
         assert hasattr(host, name), f"{name} declared in include/q2048.h but not exported by libq2048_host.so"
     assert set(pkg._native._SIGNATURES) == declared
     L = pkg._native.lib()
-    assert L.q2048_abi_version() == pkg._native.ABI_VERSION == 6
+    assert L.q2048_abi_version() == pkg._native.ABI_VERSION == 7
     assert L.q2048_sizeof_aux() == 16 and L.q2048_sizeof_slot() == 32
     assert L.q2048_strerror(-4).decode().startswith("unsupported")
     # host-side argument validation needs no device

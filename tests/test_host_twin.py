@@ -43,6 +43,7 @@ ON_CPU = [
     "test_closed_key_set_deterministic_mode_is_bit_exact", "test_growing_table_freezes_at_its_largest_capacity",
     "test_import_reports_rows_beyond_the_learning_probe_limit", "test_adapters_follow_the_table_policy",
     "test_shared_table_writes_are_legitimate_values", "test_train_save_then_evaluate_scripts",
+    "test_line_summaries_of_a_closed_key_set",
 ]
 for _name in ON_CPU:
     globals()[_name.replace("_on_device", "") + "_on_cpu"] = getattr(_par, _name)
