@@ -76,7 +76,8 @@ ALGO_BYTES_ROW_TUPLE = 64 + 8 * 16 + 4 * 4 + 6
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 FREEZE_LOAD = 0.5           # the frozen companion: BatchedQLearningAgent's default freeze_load
-PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r06_pmc_traffic.json", "r06_pmc_traffic_k20.json")]
+PMC_TRAFFIC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r06_pmc_traffic.json", "r06_pmc_traffic_k20.json",
+                                                                 "r06_pmc_traffic_frozen_k20.json")]
 CSRC = os.path.join(REPO, "2048_q-learning_amd", "csrc")
 KERNEL_SOURCES = ("q2048_kernels.hip", "q2048_core.hpp", "q2048_core5.hpp", "q2048_luts.inc")
 
@@ -580,6 +581,15 @@ def run_rank(args):
                           "prefilled_rows": cm["prefilled_rows"], "frozen": cm["frozen"],
                           "drops_per_step": cst["drops"] / max(cst["steps"], 1),
                           "table_load_factor": cm["table_rows"] / float(1 << c_cap)})
+            if c_fill:
+                # the frozen workload has counter passes of its own (bench.py --prefill-load, tools/sessions/r06_final_a.sh)
+                c_cfg = {"boards": shard.num_envs, "steps_per_launch": c_S, "cap_log2": c_cap, "board_size": c_n,
+                         "eps": c_eps, "strict_td": bool(args.strict_td), "prefill_load": c_fill}
+                c_per_step, c_source, _ = committed_pmc_traffic(c_cfg)
+                if c_per_step is not None:
+                    comps[-1]["traffic_bytes_per_env_step"] = c_per_step
+                    comps[-1]["fabric_frac"] = c_per_step * shard.num_envs * c_steps / (cs["avg_launch_s"] * cs["launches"]) / 1e9 / HBM_PEAK_GBS
+                    comps[-1]["traffic_source"] = c_source
         out["companions"] = comps
 
     # the GPU side is done: leave the process group before the host-only leg, so that no rank
