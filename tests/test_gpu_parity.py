@@ -260,7 +260,7 @@ def test_flag_bits_outside_the_abi_are_refused(pkg):
     env = pkg.BatchedGame2048Env(64, seed=1, device=DEV)
     agent = pkg.BatchedQLearningAgent(10, capacity_log2=12, seed=1, device=DEV)
     before = env.boards.clone()
-    for bits in (1 << 8, 1 << 12, 1 << 14, 5 << 16, 1 << 24, 1 << 31):
+    for bits in (1 << 8, 1 << 12, 1 << 14, 5 << 16, 1 << 25, 1 << 31):   # (bit 24 is Q2048_FLAG_LINE_SUMMARY since ABI 7)
         agent.experiment_bits = bits
         with pytest.raises(N.NativeError, match="flag bits"):
             agent.fused_rollout(env, 3)
