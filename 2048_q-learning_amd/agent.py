@@ -1067,6 +1067,7 @@ class BatchedQLearningAgent:
             return
         keys, q = keys.to(self.device).contiguous(), q.to(self.device).contiguous()
         self.invalidate_row_cache()
+        self._summarised = False                          # (rows arrive: line summaries stop describing the table)
         N.check(self._L.q2048_table_import(_ptr(self.table), self.capacity_log2, _ptr(keys), _ptr(q), rows, words,
                                            _ptr(self.status), _stream(self.device)), "table_import")
 
