@@ -4,7 +4,8 @@
  * statistics vector, which tests/test_gpu_parity.py compares with the Python host's.
  *
  *   usage: rollout_host <boards> <steps> <seed> <cap_log2> <eps> [steps per launch, default = steps]
- *                       [grow before launch k, default = never]
+ *                       [grow before launch k, default / -1 = never]
+ *                       [close the key set before launch k, default = never]
  *
  * With more than one launch the rollouts go through q2048_fused_rollout_opts: the row every env
  * carries passes from launch to launch through a row cache (hipMalloc'd, zero-filled), and the
@@ -17,6 +18,13 @@
  * stream between launch k - 1 and launch k (q2048_table_grow_commit: returns the new table at once), and the
  * check and the hand-over of the old table happen after the last launch (q2048_table_grow_finish).  The
  * statistics it prints are those of the run on a fixed table.
+ *
+ * With the eighth argument the table CLOSES ITS KEY SET before launch k -- what a table that cannot grow any more
+ * does (the reference's dict has no limit): from then on every launch carries Q2048_FLAG_NO_NEW_ROWS
+ * (rows that exist keep learning, a state without a row reads as zeros and lives in the env's visit row -- the row
+ * cache carries it from launch to launch --, its updates are dropped and counted), and, the table being 4x4, the
+ * LINE SUMMARIES are written once (q2048_table_summarise) and Q2048_FLAG_LINE_SUMMARY makes a lookup of an absent
+ * state one request.
  */
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
@@ -38,6 +46,7 @@ int main(int argc, char **argv) {
   const double eps = argc > 5 ? atof(argv[5]) : 0.95;
   const int64_t per_launch = argc > 6 && atoll(argv[6]) > 0 ? atoll(argv[6]) : steps;
   const int64_t grow_at = argc > 7 ? atoll(argv[7]) : -1;
+  const int64_t close_at = argc > 8 ? atoll(argv[8]) : -1;
   int cap_now = cap_log2;
 
   uint8_t *boards; q2048_aux *aux; q2048_slot *table; int64_t *stats_i; double *stats_f; uint32_t *status;
@@ -77,6 +86,7 @@ int main(int argc, char **argv) {
     opts.size = (uint32_t)sizeof opts;
     opts.row_cache = cache; opts.stats_mirror = mirror; opts.mirror_ticket = ticket;
     uint64_t launches = 0;
+    uint32_t flags = 0;
     q2048_growth *growth = NULL;
     int64_t moved = -1;
     if (grow_at >= 0) CHECK_Q(q2048_table_grow_begin(table, cap_now, cap_now + 2, &growth));   /* returns at once */
@@ -89,8 +99,13 @@ int main(int argc, char **argv) {
         CHECK_HIP(hipMemsetAsync(cache, 0, (size_t)B * q2048_sizeof_rowcache(4), NULL));
         cap_now += 2;
       }
+      if ((int64_t)launches == close_at) {
+        /* the key set closes here: nothing creates a row from now on, so the summaries written now stay true */
+        CHECK_Q(q2048_table_summarise(table, cap_now, NULL));
+        flags = Q2048_FLAG_NO_NEW_ROWS | Q2048_FLAG_LINE_SUMMARY;
+      }
       CHECK_Q(q2048_fused_rollout_opts(boards, aux, table, cap_now, B, 4, k, eps, 0.1, 0.99, seed, 0,
-                                       (uint32_t)done, 0, stats_i, stats_f, status, &opts, NULL));
+                                       (uint32_t)done, flags, stats_i, stats_f, status, &opts, NULL));
     }
     if (growth != NULL) {
       if (cap_now == cap_log2) CHECK_Q(q2048_table_grow_abort(growth));          /* never committed */

@@ -2171,16 +2171,28 @@ def test_c_host_program_drives_the_abi(pkg, tmp_path):
     # with a row cache and the statistics read from the host-side mirror
     # ... and the same launches on a table that grows fourfold before launch 2, off the critical path
     # (q2048_table_reserve / _grow_begin / _grow_commit / _grow_finish from plain C): the same run
-    for per_launch, grow_at in ((0, None), (16, None), (16, 2)):
-        argv = [exe, str(B), str(steps), str(seed), str(cap), str(eps), str(per_launch)] + ([str(grow_at)] if grow_at is not None else [])
+    # ... and on a table that CLOSES ITS KEY SET before launch 2 (Q2048_FLAG_NO_NEW_ROWS; q2048_table_summarise +
+    # Q2048_FLAG_LINE_SUMMARY from plain C): the Python host's run with `agent.frozen = True` from that launch on
+    env_c = pkg.BatchedGame2048Env(B, seed=seed, device=DEV)
+    agent_c = pkg.BatchedQLearningAgent(100, learning_rate=0.1, discount_factor=0.99, exploration_rate=eps,
+                                        capacity_log2=cap, seed=seed, device=DEV, freeze_load=None)
+    for launch, at in enumerate(range(0, steps, 16)):
+        agent_c.frozen = launch >= 2
+        agent_c.fused_rollout(env_c, min(16, steps - at))
+    st_c = agent_c.stats()
+    assert st_c["drops"] > 0 and agent_c._summarised
+    for per_launch, grow_at, close_at in ((0, None, None), (16, None, None), (16, 2, None), (16, -1, 2)):
+        argv = [exe, str(B), str(steps), str(seed), str(cap), str(eps), str(per_launch)] + (
+            [str(grow_at)] if grow_at is not None else []) + ([str(close_at)] if close_at is not None else [])
         out = subprocess.run(argv, check=True, capture_output=True, text=True).stdout
         got = json.loads(out.strip().splitlines()[-1])
-        assert got["capacity_log2"] == cap + (2 if grow_at is not None else 0)
+        want, want_agent, want_env = (st, agent, env) if close_at is None else (st_c, agent_c, env_c)
+        assert got["capacity_log2"] == cap + (2 if grow_at is not None and grow_at >= 0 else 0)
         for k in ("steps", "episodes", "valid_moves", "score_sum", "inserts", "drops", "explored"):
-            assert got[k] == st[k], (per_launch, grow_at, k)
-        assert got["rows"] == agent.table_size() and got["status"] == 0
-        assert got["board0"] == env.boards[0].cpu().tolist()
-        assert np.isclose(got["return_sum"], st["return_sum"], rtol=1e-9)
+            assert got[k] == want[k], (per_launch, grow_at, close_at, k)
+        assert got["rows"] == want_agent.table_size() and got["status"] == 0
+        assert got["board0"] == want_env.boards[0].cpu().tolist()
+        assert np.isclose(got["return_sum"], want["return_sum"], rtol=1e-9)
 
 
 @pytest.mark.parametrize("n,B,steps,sort_bits", [(4, 3000, 80, 0), (5, 1500, 60, 0), (4, 60000, 24, 0),
