@@ -159,7 +159,7 @@ extern "C" {
                                      (absent: done) or carries the key's fingerprint (that slot's head, one more
                                      request, settles it).  The slot-by-slot probe sends 2.35 requests per lookup on a
                                      table at load 0.5 and the step takes 47.9 us per 2^20 boards; with summaries
-                                     1.1-1.5 and 27-33 us.  Same results, request for request fewer.
+                                     1.25 and 34.8 us (28.7 on 64-step launches).  Same results, fewer requests.
                                      CONTRACT: the summaries describe the key set as it was when q2048_table_summarise
                                      ran.  Creating a row afterwards (any call without Q2048_FLAG_NO_NEW_ROWS, an import)
                                      makes them stale, and a stale summary HIDES rows: summarise again before the flag is
